@@ -1,0 +1,205 @@
+/* raytracing_amd.h -- C ABI of the MI355X (gfx950) path-tracing pass.
+ *
+ * Drop-in boundary for ONE path of lxtyin/Raytracing: the per-pixel path-tracing pass
+ * that the reference runs as an OpenGL fragment shader behind its
+ * Renderer / ResourceManager / SSBOBuffer classes.  Every entry point below names
+ * the reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns PT_OK (0) or a negative pt_status; pt_last_error()
+ *     returns a thread-local message for the last failure on the calling thread.
+ *     (The reference has no error channel at all: GL errors are dropped and shader
+ *     failures go to std::cerr, src/renderpass/RenderPass.cpp:60-84.)
+ *   - plain pointers and sizes only; handles are opaque.
+ *   - one context per GPU; calls on a context are serialised by the caller, as the
+ *     reference's single GL thread serialises its own (main.cpp:153-354).
+ *   - draw / intersect / uploads are asynchronous on the context's stream;
+ *     pt_buf_download and pt_ctx_synchronize wait for it.
+ *   - the host-side helpers (pt_host_*) never touch a GPU.
+ */
+#ifndef RAYTRACING_AMD_H
+#define RAYTRACING_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,   /* bad argument / handle / size */
+    PT_ERR_HIP = -2,       /* a HIP runtime call failed; message has hipGetErrorString */
+    PT_ERR_STATE = -3,     /* call sequence error, e.g. draw with a scene slot unbound */
+    PT_ERR_UNSUPPORTED = -4
+} pt_status;
+
+typedef struct pt_ctx pt_ctx;
+typedef struct pt_buf pt_buf;
+typedef struct pt_tex pt_tex;
+typedef struct pt_pass pt_pass;
+
+const char *pt_last_error(void);
+/* Library version string, e.g. "raytracing_amd 0.1 (gfx950)". */
+const char *pt_version(void);
+
+/* ---- context: replaces the GL context created in main.cpp:400-416 ------------------ */
+int pt_ctx_create(int device_id, pt_ctx **out);
+int pt_ctx_destroy(pt_ctx *ctx);
+int pt_ctx_synchronize(pt_ctx *ctx);
+/* the hipStream_t all work of this context is queued on (for event timing by callers) */
+void *pt_ctx_stream(pt_ctx *ctx);
+
+/* ---- buffers: SSBOBuffer<T>, src/SSBOBuffer.h:19-150 ------------------------------- */
+/* SSBOBuffer(uint siz) / SSBOBuffer(uint siz, T* data), :93-124.  bytes may be 0
+ * (the reference creates zero-length buffers, e.g. no lights); host may be NULL. */
+int pt_buf_create(pt_ctx *ctx, size_t bytes, const void *host, pt_buf **out);
+/* release(), :81-85 */
+int pt_buf_release(pt_buf *buf);
+/* copy(const T* data), :64-70: overwrite the whole buffer from host memory */
+int pt_buf_upload(pt_buf *buf, const void *host, size_t bytes);
+/* copy(const SSBOBuffer<T>*), :132-143: device to device, sizes must match */
+int pt_buf_copy(pt_buf *dst, const pt_buf *src);
+/* fill(const T& val), :72-79: repeat one element of elem_bytes (1, 2, 4, 8, 12 or 16) */
+int pt_buf_fill(pt_buf *buf, const void *elem, size_t elem_bytes);
+/* the glMapBufferRange read-back of save_as_image, :45-46 (synchronises the stream) */
+int pt_buf_download(const pt_buf *buf, void *host, size_t bytes);
+size_t pt_buf_bytes(const pt_buf *buf);
+/* raw device address, for interop (torch / RCCL); stays valid until release */
+void *pt_buf_device_ptr(const pt_buf *buf);
+
+/* ---- textures: Texture::load_to_gpu, src/texture/Texture.cpp:7-36 and the two float
+ *      sky textures of Skybox::load_to_gpu, src/texture/Skybox.cpp:55-84 ------------- */
+typedef enum pt_tex_format { PT_TEX_U8 = 0, PT_TEX_F32 = 1 } pt_tex_format;
+/* REPEAT wrap, LINEAR filter, no mipmaps in use (Texture.cpp:24-27).  Row 0 of data is
+ * texture coordinate t = 0.  channels: 1, 3 or 4. */
+int pt_tex_create(pt_ctx *ctx, int width, int height, int channels, int format, const void *data, pt_tex **out);
+int pt_tex_release(pt_tex *tex);
+/* the 64-bit value to store in the texture-handle buffer (slot 0); plays the role of
+ * glGetTextureHandleARB, Texture.cpp:31.  Never 0 for a live texture. */
+uint64_t pt_tex_handle(const pt_tex *tex);
+
+/* ---- the pass: Renderer, src/renderpass/Renderer.{h,cpp} ----------------------------- */
+/* Parameters that reach the reference shader as GL uniforms (main.cpp:185-205,
+ * Renderer.cpp:40; declarations shader/pathtracing.glsl:112-141).  Matrices are column
+ * major like glm::value_ptr. */
+typedef struct pt_params {
+    float jitter[2];
+    uint32_t currentspp;
+    float skybox_Light_SUM;
+    float v2wMat[16];
+    int32_t SCREEN_W, SCREEN_H, WINDOW_W, WINDOW_H;
+    int32_t MAX_DEPTH;
+    float cameraNear, cameraFar;
+    uint32_t frameCounter;
+    float fov;
+    int32_t SKY_W, SKY_H;
+    float backprojMat[16];
+    int32_t BRDFSampling, SkyboxSampling, SkyboxLighting, RasterizaionFor1st;
+    int32_t lightCount;
+    /* Extension with no counterpart in the reference; 0 keeps reference behaviour.
+     * accum_mode 0: outputs directLum/indirectLum/albedo hold the running mean
+     *   mix(last, cur, 1/currentspp) when currentspp != 1 (pathtracing.glsl:657-670).
+     * accum_mode 1: they hold plain sums (cur is added; currentspp == 1 still
+     *   overwrites) so that sample slices rendered on several GPUs can be summed. */
+    int32_t accum_mode;
+    int32_t reserved[7];
+} pt_params;
+
+/* Renderer::Renderer, Renderer.cpp:19-27: allocates the seven outputs for W x H. */
+int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out);
+/* Renderer::~Renderer, Renderer.cpp:56-64 */
+int pt_pass_destroy(pt_pass *pass);
+
+/* input slots, Renderer.cpp:32-38 */
+enum {
+    PT_SLOT_TEXTURE_HANDLES = 0, /* uint64 handles from pt_tex_handle            */
+    PT_SLOT_MATERIAL = 1,        /* float stream, 7 or 8 floats per record       */
+    PT_SLOT_TRIANGLE = 2,        /* 96-byte triangles                            */
+    PT_SLOT_INSTANCE_INFO = 3,   /* 112-byte records                             */
+    PT_SLOT_MESH_BVH = 4,        /* 48-byte nodes                                */
+    PT_SLOT_SCENE_BVH = 5,       /* 48-byte nodes                                */
+    PT_SLOT_LIGHT = 6            /* 32-byte records                              */
+};
+/* SSBOBuffer::bind_current_shader(index) for the seven scene inputs.  The pass keeps
+ * the pointer, not a copy; rebinding or re-uploading a bound buffer is picked up by
+ * the next draw (the reference re-uploads the scene every frame, main.cpp:155-159). */
+int pt_pass_bind(pt_pass *pass, int slot, pt_buf *buf);
+/* RenderPass::bind_texture(name, ...), RenderPass.cpp:123-128.  Names understood:
+ * "skybox", "skybox_samplecache" (main.cpp:179-180). */
+int pt_pass_bind_texture(pt_pass *pass, const char *name, pt_tex *tex);
+int pt_pass_set_params(pt_pass *pass, const pt_params *params);
+/* Renderer::draw(), Renderer.cpp:30-54: one sample per pixel for the whole frame. */
+int pt_pass_draw(pt_pass *pass);
+
+/* output members of Renderer (Renderer.h:19-25), by the SSBO slot the shader writes
+ * (pathtracing.glsl:88-110) */
+enum {
+    PT_OUT_ALBEDO = 7,          /* W*H*3 */
+    PT_OUT_MOTION = 9,          /* W*H*2 */
+    PT_OUT_DEPTH = 11,          /* W*H   */
+    PT_OUT_NORMAL = 12,         /* W*H*3 */
+    PT_OUT_INSTANCE_INDEX = 13, /* W*H   */
+    PT_OUT_DIRECT_LUM = 14,     /* W*H*3 */
+    PT_OUT_INDIRECT_LUM = 15    /* W*H*3 */
+};
+/* Borrowed handle, owned by the pass. */
+int pt_pass_output(pt_pass *pass, int which, pt_buf **out);
+
+/* Work counters accumulated by draw / intersect since the last reset. */
+typedef struct pt_stats {
+    uint64_t samples;        /* pixels shaded (one per pixel per draw)            */
+    uint64_t rays_extend;    /* closest-hit queries: primary + indirect           */
+    uint64_t rays_shadow;    /* occlusion queries: sky NEE + light shadow rays    */
+    uint64_t draws;
+    uint64_t reserved[4];
+} pt_stats;
+int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
+
+/* Closest hit for n rays against the scene bound to the pass: intersect_sceneBVH,
+ * shader/pathtracing.glsl:292-316, exposed on its own.  rays: n * 6 floats
+ * (origin xyz, direction xyz; the direction is used as given).  hits: n records. */
+typedef struct pt_hit {
+    int32_t instance; /* -1 on a miss                                            */
+    int32_t triangle; /* index into the triangle buffer, -1 on a miss            */
+    float t;          /* 1e18 on a miss (INF of shader/basic/math.glsl:1)        */
+    float u, v;       /* barycentrics of vertices 1 and 2                        */
+} pt_hit;
+int pt_pass_intersect(pt_pass *pass, const pt_buf *rays, size_t n, pt_buf *hits);
+
+/* ---- host-side scene helpers (no GPU) ------------------------------------------------ */
+/* Mesh::build_meshBVH + ResourceManager::reload_meshes, src/instance/Mesh.cpp:10-22,
+ * src/ResourceManager.cpp:95-140.  tris: concatenated 96-byte triangles, tri_count[m]
+ * per mesh.  nodes_out must hold sum(2*tri_count[m]-1) 48-byte nodes.  root_box_out:
+ * 6 floats per mesh (min xyz, max xyz).  siz_out/depth_out: per mesh tree. */
+int pt_host_build_mesh_bvh(const void *tris, const int32_t *tri_count, int32_t n_mesh, int32_t n_threads,
+                           void *nodes_out, float *root_box_out, int32_t *siz_out, int32_t *depth_out);
+/* ResourceManager::reload_scene, src/ResourceManager.cpp:200-224 (+ :146-198) for an
+ * already walked instance list.  l2w: 16 floats per instance.  instance_info_out:
+ * n_inst 112-byte records; scene_nodes_out: 2*n_inst-1 48-byte nodes;
+ * stats_out[2] = {siz, depth} of the two-level tree as BVHNode::build books them. */
+int pt_host_build_scene(const float *mesh_root_box, const int32_t *mesh_siz, const int32_t *mesh_depth,
+                        int32_t n_mesh, const float *l2w, const int32_t *mesh_index, const int32_t *material_ptr,
+                        int32_t n_inst, void *instance_info_out, void *scene_nodes_out, int32_t *stats_out);
+/* Transform::matrix, src/Transform.cpp:20-53 */
+int pt_host_transform_matrix(const float position[3], const float rotation_deg[3], const float scale[3],
+                             float out16[16]);
+/* glm mat4 * mat4 / inverse as the reference uses them for the hierarchy walk and
+ * InstanceInfo (ResourceManager.cpp:75,154) */
+int pt_host_mat4_mul(const float a[16], const float b[16], float out16[16]);
+int pt_host_mat4_inverse(const float m[16], float out16[16]);
+/* Camera::projection, src/instance/Camera.cpp:21-43 */
+int pt_host_camera_projection(float fov_x, float far_plane, int32_t screen_w, int32_t screen_h, float out16[16]);
+/* HDRLoader::load, include/hdrloader.cpp:29-116, from memory.  Call with rgb_out NULL
+ * to get the size. */
+int pt_host_rgbe_decode(const void *bytes, size_t n, int32_t *w, int32_t *h, float *rgb_out);
+/* Writes a flat Radiance picture; returns the byte count (call with out NULL first). */
+int64_t pt_host_rgbe_encode(const float *rgb, int32_t w, int32_t h, void *out, size_t cap);
+/* Skybox::load_to_gpu's CPU half, src/texture/Skybox.cpp:12-53 */
+int pt_host_sky_cache(const float *rgb, int32_t w, int32_t h, float *cache_out, double *light_sum_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACING_AMD_H */

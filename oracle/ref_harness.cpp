@@ -1,0 +1,218 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, imported by or executed from the
+// product library.  Only tests/, bench.py's cpu_baseline leg and fixture generators
+// may run the binary this file builds.
+//
+// Driver around the reference's OWN compiled sources.  The Makefile next to this
+// file compiles, from where they lie under /root/reference (nothing is copied):
+//   src/BVH.cpp  src/AABB.cpp  src/Intersection.cpp
+//   include/hdrloader.cpp  include/stb_image.cpp
+// and links them with this driver into oracle/_ref/ref_harness.  Everything
+// numerical (SAH build, std::sort tie order, slab / Moller-Trumbore tests, RGBE
+// decode, JPEG decode, glm::inverse) is executed by reference code; this file only
+// moves bytes in and out and restates the two GL-entangled loops that cannot be
+// compiled headless:
+//   - Mesh::build_meshBVH            (src/instance/Mesh.cpp:10-22)
+//   - ResourceManager::reload_meshes (src/ResourceManager.cpp:116-140, BFS flatten)
+//
+// File protocol (little endian, tightly packed):
+//   meshes file : i32 nmesh ; per mesh { i32 ntri ; f32 pos[ntri*9] }
+//   bvh out     : i32 nnodes ; node[nnodes]{f32 aa[4]; f32 bb[4]; i32 ls, rs, inst, tri}
+//                 ; per mesh { i32 siz ; i32 depth }
+//   scene file  : i32 ninst ; per inst { f32 l2w[16] (column major) ; i32 mesh }
+//   rays file   : i32 nrays ; f32 ray[nrays*6] (ox oy oz dx dy dz)
+//   hits out    : per ray { i32 inst ; i32 tri (global) ; f32 t }   (-1,-1,1e18 = miss)
+#include "BVH.h"
+#include "hdrloader.h"
+#include "stb_image.h"
+#include "glm/glm.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <queue>
+#include <map>
+#include <string>
+#include <vector>
+
+struct FlatNode { float aa[4], bb[4]; int ls, rs, inst, tri; };
+
+static std::vector<char> slurp(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if(!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<char> b(n);
+    if(n && fread(b.data(), 1, n, f) != (size_t)n) { fprintf(stderr, "short read %s\n", path); exit(2); }
+    fclose(f);
+    return b;
+}
+
+struct MeshSet {
+    std::vector<std::vector<Triangle>> tris;
+    std::vector<BVHNode*> roots;
+    std::vector<int> triBase;
+};
+
+static void load_meshes(const char *path, MeshSet &ms) {
+    std::vector<char> b = slurp(path);
+    const char *p = b.data();
+    int nmesh; memcpy(&nmesh, p, 4); p += 4;
+    ms.tris.resize(nmesh);
+    int base = 0;
+    for(int m = 0; m < nmesh; m++) {
+        int ntri; memcpy(&ntri, p, 4); p += 4;
+        ms.tris[m].resize(ntri);
+        for(int i = 0; i < ntri; i++) {
+            float v[9]; memcpy(v, p, 36); p += 36;
+            for(int k = 0; k < 3; k++) ms.tris[m][i].vertex[k] = vec3(v[k*3], v[k*3+1], v[k*3+2]);
+        }
+        ms.triBase.push_back(base);
+        base += ntri;
+    }
+    for(int m = 0; m < nmesh; m++) {
+        // Mesh::build_meshBVH, src/instance/Mesh.cpp:10-22
+        std::vector<BVHPrimitive> primitives;
+        for(Triangle &t: ms.tris[m]) {
+            BVHPrimitive tmp;
+            tmp.trianglePtr = &t;
+            for(auto &v: t.vertex) tmp.aabb.addPoint(v);
+            primitives.push_back(tmp);
+        }
+        ms.roots.push_back(BVHNode::build(primitives));   // reference code
+    }
+}
+
+static int cmd_bvh(const char *in, const char *out) {
+    MeshSet ms; load_meshes(in, ms);
+    // ResourceManager::reload_meshes, src/ResourceManager.cpp:116-140
+    std::vector<FlatNode> flat;
+    std::queue<BVHNode*> q;
+    for(auto r: ms.roots) q.push(r);
+    int N = (int)ms.roots.size();
+    // triangle pointer -> global index (triangleIndexMap)
+    std::map<Triangle*, int> triIndex;
+    for(size_t m = 0; m < ms.tris.size(); m++)
+        for(size_t i = 0; i < ms.tris[m].size(); i++) triIndex[&ms.tris[m][i]] = ms.triBase[m] + (int)i;
+    while(!q.empty()) {
+        BVHNode *p = q.front(); q.pop();
+        int il = -1, ir = -1;
+        if(p->ls) il = N++, q.emplace(p->ls);
+        if(p->rs) ir = N++, q.emplace(p->rs);
+        FlatNode y;
+        y.aa[0] = p->aabb.mi.x; y.aa[1] = p->aabb.mi.y; y.aa[2] = p->aabb.mi.z; y.aa[3] = 0;
+        y.bb[0] = p->aabb.mx.x; y.bb[1] = p->aabb.mx.y; y.bb[2] = p->aabb.mx.z; y.bb[3] = 0;
+        y.ls = il; y.rs = ir; y.inst = -1; y.tri = -1;
+        if(p->trianglePtr) y.tri = triIndex[p->trianglePtr];
+        flat.push_back(y);
+    }
+    FILE *f = fopen(out, "wb");
+    int n = (int)flat.size();
+    fwrite(&n, 4, 1, f);
+    fwrite(flat.data(), sizeof(FlatNode), flat.size(), f);
+    for(auto r: ms.roots) { fwrite(&r->siz, 4, 1, f); fwrite(&r->depth, 4, 1, f); }
+    fclose(f);
+    return 0;
+}
+
+// CPU picking path: BVHNode::rayIntersect (src/BVH.cpp:89-114) at mesh level.
+// The instance leaf of the reference does  w2l = inverse(matrix_to_global());
+// ray.ori = w2l*vec4(ori,1); ray.dir = w2l*vec4(dir,0)  (BVH.cpp:91-93) and descends;
+// Instance/Transform cannot be linked headless, so the same three statements are
+// executed here with the l2w matrix read from the scene file, for every instance in
+// turn (the scene-level tree only culls; it never changes which triangle is closest
+// except through t ties).
+static int cmd_isect(const char *meshes, const char *scene, const char *rays, const char *out) {
+    MeshSet ms; load_meshes(meshes, ms);
+    std::map<Triangle*, int> triIndex;
+    for(size_t m = 0; m < ms.tris.size(); m++)
+        for(size_t i = 0; i < ms.tris[m].size(); i++) triIndex[&ms.tris[m][i]] = ms.triBase[m] + (int)i;
+    std::vector<char> sb = slurp(scene);
+    const char *p = sb.data();
+    int ninst; memcpy(&ninst, p, 4); p += 4;
+    std::vector<glm::mat4> w2l(ninst); std::vector<int> meshOf(ninst);
+    for(int i = 0; i < ninst; i++) {
+        glm::mat4 l2w; memcpy(&l2w[0][0], p, 64); p += 64;
+        memcpy(&meshOf[i], p, 4); p += 4;
+        w2l[i] = glm::inverse(l2w);
+    }
+    std::vector<char> rb = slurp(rays);
+    int nrays; memcpy(&nrays, rb.data(), 4);
+    const float *r = (const float*)(rb.data() + 4);
+    FILE *f = fopen(out, "wb");
+    for(int k = 0; k < nrays; k++) {
+        vec3 ori(r[k*6], r[k*6+1], r[k*6+2]), dir(r[k*6+3], r[k*6+4], r[k*6+5]);
+        Intersection isect;
+        int hitInst = -1;
+        for(int i = 0; i < ninst; i++) {
+            vec3 o = w2l[i] * vec4(ori, 1);
+            vec3 d = w2l[i] * vec4(dir, 0);
+            Ray ray(o, d);
+            Triangle *before = isect.trianglePtr;
+            float tb = isect.t;
+            ms.roots[meshOf[i]]->rayIntersect(ray, isect, nullptr);
+            if(isect.trianglePtr != before || isect.t != tb) hitInst = i;
+        }
+        int tri = isect.exist ? triIndex[isect.trianglePtr] : -1;
+        if(!isect.exist) hitInst = -1;
+        // the same Triangle object is shared by every instance of a mesh: report the
+        // global index of the triangle inside the mesh array, as the flat buffers do
+        float t = isect.t;
+        fwrite(&hitInst, 4, 1, f); fwrite(&tri, 4, 1, f); fwrite(&t, 4, 1, f);
+    }
+    fclose(f);
+    return 0;
+}
+
+// glm::inverse / glm mat4*mat4 as compiled from the vendored headers.
+//   in : i32 n ; f32 m[n*16]      out: f32 inv[n*16] ; f32 prod[16] (m0*m1*...*m(n-1))
+static int cmd_mat(const char *in, const char *out) {
+    std::vector<char> b = slurp(in);
+    int n; memcpy(&n, b.data(), 4);
+    const float *m = (const float*)(b.data() + 4);
+    FILE *f = fopen(out, "wb");
+    glm::mat4 prod(1.0f);
+    for(int i = 0; i < n; i++) {
+        glm::mat4 a; memcpy(&a[0][0], m + i*16, 64);
+        glm::mat4 inv = glm::inverse(a);
+        fwrite(&inv[0][0], 4, 16, f);
+        prod = prod * a;
+    }
+    fwrite(&prod[0][0], 4, 16, f);
+    fclose(f);
+    return 0;
+}
+
+static int cmd_hdr(const char *in, const char *out) {
+    HDRLoaderResult res; res.width = res.height = 0; res.cols = nullptr;
+    if(!HDRLoader::load(in, res)) { fprintf(stderr, "HDRLoader::load failed\n"); return 1; }
+    FILE *f = fopen(out, "wb");
+    fwrite(&res.width, 4, 1, f); fwrite(&res.height, 4, 1, f);
+    fwrite(res.cols, 4, (size_t)res.width * res.height * 3, f);
+    fclose(f);
+    return 0;
+}
+
+// stbi_load_from_memory exactly as loader.cpp:23-27 calls it (no vertical flip,
+// channels as stored).   out: i32 w, h, c ; u8 data[w*h*c]
+static int cmd_stb(const char *in, const char *out) {
+    std::vector<char> b = slurp(in);
+    int w, h, c;
+    unsigned char *d = stbi_load_from_memory((unsigned char*)b.data(), (int)b.size(), &w, &h, &c, 0);
+    if(!d) { fprintf(stderr, "stbi failed\n"); return 1; }
+    FILE *f = fopen(out, "wb");
+    fwrite(&w, 4, 1, f); fwrite(&h, 4, 1, f); fwrite(&c, 4, 1, f);
+    fwrite(d, 1, (size_t)w * h * c, f);
+    fclose(f);
+    stbi_image_free(d);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    std::string c = argc > 1 ? argv[1] : "";
+    if(c == "bvh" && argc == 4) return cmd_bvh(argv[2], argv[3]);
+    if(c == "isect" && argc == 6) return cmd_isect(argv[2], argv[3], argv[4], argv[5]);
+    if(c == "mat" && argc == 4) return cmd_mat(argv[2], argv[3]);
+    if(c == "hdr" && argc == 4) return cmd_hdr(argv[2], argv[3]);
+    if(c == "stb" && argc == 4) return cmd_stb(argv[2], argv[3]);
+    fprintf(stderr, "usage: ref_harness bvh <meshes> <out> | isect <meshes> <scene> <rays> <out> | "
+                    "mat <in> <out> | hdr <file.hdr> <out> | stb <image> <out>\n");
+    return 2;
+}

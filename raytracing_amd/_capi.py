@@ -1,0 +1,107 @@
+"""ctypes binding of include/raytracing_amd.h.
+
+The shared library is built in-tree by raytracing_amd.build; importing this module
+fails loudly when it is missing -- there is no Python or CPU fallback for the pass.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libraytracing_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "raytracing_amd: %s is missing. Build it with `python -m raytracing_amd.build` "
+        "(needs hipcc; cross-compiles for gfx950 without a GPU)." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+c_void_pp = C.POINTER(C.c_void_p)
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+
+
+class PtParams(C.Structure):
+    _fields_ = [
+        ("jitter", C.c_float * 2),
+        ("currentspp", C.c_uint32),
+        ("skybox_Light_SUM", C.c_float),
+        ("v2wMat", C.c_float * 16),
+        ("SCREEN_W", C.c_int32), ("SCREEN_H", C.c_int32),
+        ("WINDOW_W", C.c_int32), ("WINDOW_H", C.c_int32),
+        ("MAX_DEPTH", C.c_int32),
+        ("cameraNear", C.c_float), ("cameraFar", C.c_float),
+        ("frameCounter", C.c_uint32),
+        ("fov", C.c_float),
+        ("SKY_W", C.c_int32), ("SKY_H", C.c_int32),
+        ("backprojMat", C.c_float * 16),
+        ("BRDFSampling", C.c_int32), ("SkyboxSampling", C.c_int32),
+        ("SkyboxLighting", C.c_int32), ("RasterizaionFor1st", C.c_int32),
+        ("lightCount", C.c_int32),
+        ("accum_mode", C.c_int32),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
+class PtStats(C.Structure):
+    _fields_ = [
+        ("samples", C.c_uint64), ("rays_extend", C.c_uint64), ("rays_shadow", C.c_uint64),
+        ("draws", C.c_uint64), ("reserved", C.c_uint64 * 4),
+    ]
+
+
+# name -> (restype, argtypes); also the list the symbol-export test walks
+SIGNATURES = {
+    "pt_last_error": (C.c_char_p, []),
+    "pt_version": (C.c_char_p, []),
+    "pt_ctx_create": (C.c_int, [C.c_int, c_void_pp]),
+    "pt_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "pt_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "pt_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "pt_buf_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, c_void_pp]),
+    "pt_buf_release": (C.c_int, [C.c_void_p]),
+    "pt_buf_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pt_buf_copy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pt_buf_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pt_buf_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pt_buf_bytes": (C.c_size_t, [C.c_void_p]),
+    "pt_buf_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "pt_tex_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_void_pp]),
+    "pt_tex_release": (C.c_int, [C.c_void_p]),
+    "pt_tex_handle": (C.c_uint64, [C.c_void_p]),
+    "pt_pass_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_void_pp]),
+    "pt_pass_destroy": (C.c_int, [C.c_void_p]),
+    "pt_pass_bind": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "pt_pass_bind_texture": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "pt_pass_set_params": (C.c_int, [C.c_void_p, C.POINTER(PtParams)]),
+    "pt_pass_draw": (C.c_int, [C.c_void_p]),
+    "pt_pass_output": (C.c_int, [C.c_void_p, C.c_int, c_void_pp]),
+    "pt_pass_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats), C.c_int]),
+    "pt_pass_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pt_host_build_mesh_bvh": (C.c_int, [C.c_void_p, i32p, C.c_int32, C.c_int32, C.c_void_p, f32p, i32p, i32p]),
+    "pt_host_build_scene": (C.c_int, [f32p, i32p, i32p, C.c_int32, f32p, i32p, i32p, C.c_int32,
+                                      C.c_void_p, C.c_void_p, i32p]),
+    "pt_host_transform_matrix": (C.c_int, [f32p, f32p, f32p, f32p]),
+    "pt_host_mat4_mul": (C.c_int, [f32p, f32p, f32p]),
+    "pt_host_mat4_inverse": (C.c_int, [f32p, f32p]),
+    "pt_host_camera_projection": (C.c_int, [C.c_float, C.c_float, C.c_int32, C.c_int32, f32p]),
+    "pt_host_rgbe_decode": (C.c_int, [C.c_void_p, C.c_size_t, i32p, i32p, f32p]),
+    "pt_host_rgbe_encode": (C.c_int64, [f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    "pt_host_sky_cache": (C.c_int, [f32p, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_double)]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class PtError(RuntimeError):
+    pass
+
+
+def check(code):
+    """Raises PtError with the library's message when code is not PT_OK."""
+    if code < 0:
+        raise PtError("%s (status %d)" % (lib.pt_last_error().decode("utf-8", "replace"), code))
+    return code

@@ -1,0 +1,145 @@
+// Host-only half of the C ABI: scene-buffer producers.  Nothing here calls HIP.
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "capi_common.h"
+#include "host/bvh_builder.h"
+#include "host/scene_host.h"
+#include "host/sky_host.h"
+
+namespace rta {
+static thread_local std::string g_last_error;
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+}  // namespace rta
+
+using namespace rta;
+
+extern "C" {
+
+const char *pt_last_error(void) { return g_last_error.c_str(); }
+const char *pt_version(void) { return "raytracing_amd 0.1 (gfx950)"; }
+
+int pt_host_build_mesh_bvh(const void *tris, const int32_t *tri_count, int32_t n_mesh, int32_t n_threads,
+                           void *nodes_out, float *root_box_out, int32_t *siz_out, int32_t *depth_out) {
+    if(!tris || !tri_count || n_mesh <= 0 || !nodes_out) return fail(PT_ERR_INVALID, "pt_host_build_mesh_bvh: null argument or n_mesh <= 0");
+    for(int m = 0; m < n_mesh; m++)
+        if(tri_count[m] <= 0) return fail(PT_ERR_INVALID, "pt_host_build_mesh_bvh: every mesh needs at least one triangle");
+    if(n_threads <= 0) {
+        unsigned hc = std::thread::hardware_concurrency();
+        n_threads = hc ? (hc > 16 ? 16 : (int)hc) : 1;
+    }
+    MeshSet ms;
+    build_mesh_set(static_cast<const TriangleRec *>(tris), tri_count, n_mesh, n_threads, ms);
+    memcpy(nodes_out, ms.nodes.data(), ms.nodes.size() * sizeof(BVHNodeInfo));
+    for(int m = 0; m < n_mesh; m++) {
+        if(root_box_out) {
+            for(int k = 0; k < 3; k++) {
+                root_box_out[m * 6 + k] = ms.root_box[m].mi[k];
+                root_box_out[m * 6 + 3 + k] = ms.root_box[m].mx[k];
+            }
+        }
+        if(siz_out) siz_out[m] = ms.siz[m];
+        if(depth_out) depth_out[m] = ms.depth[m];
+    }
+    return PT_OK;
+}
+
+int pt_host_build_scene(const float *mesh_root_box, const int32_t *mesh_siz, const int32_t *mesh_depth,
+                        int32_t n_mesh, const float *l2w, const int32_t *mesh_index, const int32_t *material_ptr,
+                        int32_t n_inst, void *instance_info_out, void *scene_nodes_out, int32_t *stats_out) {
+    if(!mesh_root_box || !l2w || !mesh_index || !material_ptr || !instance_info_out || !scene_nodes_out)
+        return fail(PT_ERR_INVALID, "pt_host_build_scene: null argument");
+    if(n_mesh <= 0 || n_inst <= 0) return fail(PT_ERR_INVALID, "pt_host_build_scene: needs at least one mesh and one instance");
+    MeshSet ms;
+    ms.root_box.resize(n_mesh);
+    ms.siz.assign(n_mesh, 1);
+    ms.depth.assign(n_mesh, 1);
+    for(int m = 0; m < n_mesh; m++) {
+        for(int k = 0; k < 3; k++) {
+            ms.root_box[m].mi[k] = mesh_root_box[m * 6 + k];
+            ms.root_box[m].mx[k] = mesh_root_box[m * 6 + 3 + k];
+        }
+        if(mesh_siz) ms.siz[m] = mesh_siz[m];
+        if(mesh_depth) ms.depth[m] = mesh_depth[m];
+    }
+    for(int i = 0; i < n_inst; i++)
+        if(mesh_index[i] < 0 || mesh_index[i] >= n_mesh) return fail(PT_ERR_INVALID, "pt_host_build_scene: mesh index out of range");
+    std::vector<Mat4> mats(n_inst);
+    for(int i = 0; i < n_inst; i++) memcpy(mats[i].data(), l2w + i * 16, 64);
+    SceneLevel sl;
+    build_scene_level(ms, mats.data(), mesh_index, material_ptr, n_inst, sl);
+    memcpy(instance_info_out, sl.instances.data(), sl.instances.size() * sizeof(InstanceInfo));
+    memcpy(scene_nodes_out, sl.nodes.data(), sl.nodes.size() * sizeof(BVHNodeInfo));
+    if(stats_out) { stats_out[0] = sl.siz; stats_out[1] = sl.depth; }
+    return PT_OK;
+}
+
+int pt_host_transform_matrix(const float position[3], const float rotation_deg[3], const float scale[3],
+                             float out16[16]) {
+    if(!position || !rotation_deg || !scale || !out16) return fail(PT_ERR_INVALID, "pt_host_transform_matrix: null argument");
+    Mat4 m = transform_matrix(position, rotation_deg, scale);
+    memcpy(out16, m.data(), 64);
+    return PT_OK;
+}
+
+int pt_host_mat4_mul(const float a[16], const float b[16], float out16[16]) {
+    if(!a || !b || !out16) return fail(PT_ERR_INVALID, "pt_host_mat4_mul: null argument");
+    Mat4 ma, mb;
+    memcpy(ma.data(), a, 64);
+    memcpy(mb.data(), b, 64);
+    Mat4 r = mul(ma, mb);
+    memcpy(out16, r.data(), 64);
+    return PT_OK;
+}
+
+int pt_host_mat4_inverse(const float m[16], float out16[16]) {
+    if(!m || !out16) return fail(PT_ERR_INVALID, "pt_host_mat4_inverse: null argument");
+    Mat4 a;
+    memcpy(a.data(), m, 64);
+    Mat4 r = inverse(a);
+    memcpy(out16, r.data(), 64);
+    return PT_OK;
+}
+
+int pt_host_camera_projection(float fov_x, float far_plane, int32_t screen_w, int32_t screen_h, float out16[16]) {
+    if(!out16 || screen_w <= 0 || screen_h <= 0) return fail(PT_ERR_INVALID, "pt_host_camera_projection: bad argument");
+    Mat4 m = camera_projection(fov_x, far_plane, screen_w, screen_h);
+    memcpy(out16, m.data(), 64);
+    return PT_OK;
+}
+
+int pt_host_rgbe_decode(const void *bytes, size_t n, int32_t *w, int32_t *h, float *rgb_out) {
+    if(!bytes || !w || !h) return fail(PT_ERR_INVALID, "pt_host_rgbe_decode: null argument");
+    std::vector<float> rgb;
+    std::string err;
+    int ww, hh;
+    if(!rgbe_decode(static_cast<const uint8_t *>(bytes), n, ww, hh, rgb, err)) return fail(PT_ERR_INVALID, "pt_host_rgbe_decode: " + err);
+    *w = ww;
+    *h = hh;
+    if(rgb_out) memcpy(rgb_out, rgb.data(), rgb.size() * sizeof(float));
+    return PT_OK;
+}
+
+int64_t pt_host_rgbe_encode(const float *rgb, int32_t w, int32_t h, void *out, size_t cap) {
+    if(!rgb || w <= 0 || h <= 0) return fail(PT_ERR_INVALID, "pt_host_rgbe_encode: bad argument");
+    std::vector<uint8_t> bytes;
+    rgbe_encode(rgb, w, h, bytes);
+    if(out) {
+        if(cap < bytes.size()) return fail(PT_ERR_INVALID, "pt_host_rgbe_encode: output buffer too small");
+        memcpy(out, bytes.data(), bytes.size());
+    }
+    return (int64_t)bytes.size();
+}
+
+int pt_host_sky_cache(const float *rgb, int32_t w, int32_t h, float *cache_out, double *light_sum_out) {
+    if(!rgb || w <= 0 || h <= 0 || !cache_out || !light_sum_out) return fail(PT_ERR_INVALID, "pt_host_sky_cache: bad argument");
+    std::vector<float> cache;
+    sky_build_cache(rgb, w, h, cache, *light_sum_out);
+    memcpy(cache_out, cache.data(), cache.size() * sizeof(float));
+    return PT_OK;
+}
+
+}  // extern "C"
