@@ -1,0 +1,219 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes loader for oracle/liboracle.so (the CPU restatement
+of the reference's path-tracing pass, oracle/pt_oracle.cpp) and for the compiled
+reference harness oracle/_ref/ref_harness.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_HARNESS = os.path.join(_HERE, "_ref", "ref_harness")
+
+
+def build(verbose=False):
+    """Compiles liboracle.so (and _ref/ref_harness when the reference tree exists)."""
+    r = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+
+
+class OrcTexture(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("channels", C.c_int32), ("format", C.c_int32)]
+
+
+class OrcScene(C.Structure):
+    _fields_ = [("materials", C.c_void_p), ("triangles", C.c_void_p), ("instances", C.c_void_p),
+                ("mesh_nodes", C.c_void_p), ("scene_nodes", C.c_void_p), ("lights", C.c_void_p),
+                ("textures", C.POINTER(OrcTexture)), ("n_textures", C.c_int32),
+                ("skybox", OrcTexture), ("skybox_samplecache", OrcTexture)]
+
+
+class OrcOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("directLum", "indirectLum", "albedo", "motion", "depth", "normal", "instanceIndex")]
+
+
+COUNTER_FIELDS = ("rays", "scene_nodes", "mesh_inner_nodes", "leaf_tests", "hits", "max_stack", "samples",
+                  "rays_extend", "rays_shadow", "shaded_vertices", "material_evals", "ldr_tex_fetches", "sky_fetches")
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in COUNTER_FIELDS]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in COUNTER_FIELDS}
+
+
+HIT_DTYPE = np.dtype([("instance", "<i4"), ("triangle", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_sobol.restype = C.c_float
+        _lib.orc_sobol.argtypes = [C.c_uint32, C.c_uint32]
+        _lib.orc_skybox_sample_pdf.restype = C.c_float
+        _lib.orc_intersect.restype = None
+        _lib.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.orc_render.restype = None
+        _lib.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    return _lib
+
+
+def _tex(arr, fmt):
+    t = OrcTexture()
+    t.data = arr.ctypes.data
+    t.height, t.width, t.channels = arr.shape
+    t.format = fmt
+    return t
+
+
+class OracleScene:
+    """Keeps the numpy arrays alive next to the C struct that points into them."""
+
+    def __init__(self, scene_data, sky=None):
+        sd = scene_data
+        self._keep = [sd, sky]
+        s = OrcScene()
+        s.materials = sd.materials.ctypes.data
+        s.triangles = sd.triangles.ctypes.data
+        s.instances = sd.instances.ctypes.data
+        s.mesh_nodes = sd.mesh_nodes.ctypes.data
+        s.scene_nodes = sd.scene_nodes.ctypes.data
+        s.lights = sd.lights.ctypes.data if len(sd.lights) else None
+        self._tex = (OrcTexture * max(1, len(sd.textures)))()
+        for i, t in enumerate(sd.textures):
+            self._tex[i] = _tex(t, 0)
+        s.textures = self._tex
+        s.n_textures = len(sd.textures)
+        if sky is not None:
+            s.skybox = _tex(sky.rgb, 1)
+            s.skybox_samplecache = _tex(sky.cache, 1)
+        self.c = s
+        self.scene_data = sd
+        self.sky = sky
+
+    def intersect(self, rays, n_threads=0):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        cnt = OrcCounters()
+        lib().orc_intersect(C.addressof(self.c), rays.ctypes.data, len(rays), hits.ctypes.data, C.addressof(cnt), n_threads)
+        return hits, cnt.as_dict()
+
+    def render(self, params, accum=None, n_threads=0):
+        """One sample per pixel.  params: any ctypes struct laid out like pt_params.
+        accum: dict of the previous outputs (needed when currentspp != 1).
+        Returns (dict of 7 float32 arrays, counters dict)."""
+        w, h = params.SCREEN_W, params.SCREEN_H
+        shapes = dict(directLum=3, indirectLum=3, albedo=3, motion=2, depth=1, normal=3, instanceIndex=1)
+        out = {}
+        for k, c in shapes.items():
+            if accum is not None and k in accum:
+                out[k] = np.ascontiguousarray(accum[k], np.float32).copy()
+            else:
+                out[k] = np.zeros((h, w, c), np.float32)
+        o = OrcOutputs()
+        for k in shapes:
+            setattr(o, k, out[k].ctypes.data)
+        cnt = OrcCounters()
+        lib().orc_render(C.addressof(self.c), C.addressof(params), C.addressof(o), C.addressof(cnt), n_threads)
+        return out, cnt.as_dict()
+
+
+def algorithmic_bytes_per_ray(cnt):
+    """Bytes the REFERENCE data structures make one closest-hit query touch, from the
+    reference-order visit counts: 48 B per node popped (scene, mesh inner and leaf nodes),
+    36 B of vertex positions per triangle test, 24 B ray in, 12 B hit out."""
+    rays = max(1, cnt["rays"])
+    nodes = cnt["scene_nodes"] + cnt["mesh_inner_nodes"] + cnt["leaf_tests"]
+    return (48.0 * nodes + 36.0 * cnt["leaf_tests"]) / rays + 24.0 + 12.0
+
+
+# ------------------------------------------------------------------ compiled reference
+def have_ref():
+    return os.path.exists(REF_HARNESS)
+
+
+def _write_meshes(path, scene_data):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(scene_data.tri_count)))
+        base = 0
+        for n in scene_data.tri_count:
+            f.write(struct.pack("<i", int(n)))
+            f.write(np.ascontiguousarray(scene_data.triangles[base:base + n, :9]).tobytes())
+            base += int(n)
+
+
+def ref_mesh_bvh(scene_data):
+    """Runs the reference's BVHNode::build on every mesh; returns (nodes bytes as uint8
+    array of 48-byte records, siz per mesh, depth per mesh)."""
+    with tempfile.TemporaryDirectory() as d:
+        _write_meshes(d + "/m.bin", scene_data)
+        subprocess.check_call([REF_HARNESS, "bvh", d + "/m.bin", d + "/o.bin"])
+        raw = open(d + "/o.bin", "rb").read()
+    n, = struct.unpack_from("<i", raw, 0)
+    nodes = np.frombuffer(raw, np.uint8, n * 48, 4).copy()
+    st = np.frombuffer(raw, np.int32, 2 * len(scene_data.tri_count), 4 + n * 48).reshape(-1, 2)
+    return nodes, st[:, 0].copy(), st[:, 1].copy()
+
+
+def ref_intersect(scene_data, rays):
+    """Closest hits from the reference's CPU picking routine (BVHNode::rayIntersect)."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    with tempfile.TemporaryDirectory() as d:
+        _write_meshes(d + "/m.bin", scene_data)
+        with open(d + "/s.bin", "wb") as f:
+            f.write(struct.pack("<i", len(scene_data.instances)))
+            for i in range(len(scene_data.instances)):
+                f.write(np.ascontiguousarray(scene_data.l2w[i], np.float32).tobytes())
+                f.write(struct.pack("<i", int(scene_data.instances["meshIndex"][i])))
+        with open(d + "/r.bin", "wb") as f:
+            f.write(struct.pack("<i", len(rays)))
+            f.write(rays.tobytes())
+        subprocess.check_call([REF_HARNESS, "isect", d + "/m.bin", d + "/s.bin", d + "/r.bin", d + "/o.bin"])
+        raw = open(d + "/o.bin", "rb").read()
+    return np.frombuffer(raw, np.dtype([("instance", "<i4"), ("triangle", "<i4"), ("t", "<f4")]), len(rays)).copy()
+
+
+def ref_mat_inverse(mats):
+    mats = np.ascontiguousarray(mats, np.float32).reshape(-1, 16)
+    with tempfile.TemporaryDirectory() as d:
+        with open(d + "/i.bin", "wb") as f:
+            f.write(struct.pack("<i", len(mats)))
+            f.write(mats.tobytes())
+        subprocess.check_call([REF_HARNESS, "mat", d + "/i.bin", d + "/o.bin"])
+        raw = np.fromfile(d + "/o.bin", np.float32)
+    return raw[:len(mats) * 16].reshape(-1, 16), raw[len(mats) * 16:]
+
+
+def ref_hdr_decode(hdr_bytes):
+    with tempfile.TemporaryDirectory() as d:
+        open(d + "/i.hdr", "wb").write(hdr_bytes)
+        subprocess.check_call([REF_HARNESS, "hdr", d + "/i.hdr", d + "/o.bin"])
+        raw = open(d + "/o.bin", "rb").read()
+    w, h = struct.unpack_from("<ii", raw, 0)
+    return np.frombuffer(raw, np.float32, w * h * 3, 8).reshape(h, w, 3).copy()
+
+
+def ref_stb_decode(image_bytes):
+    with tempfile.TemporaryDirectory() as d:
+        open(d + "/i.img", "wb").write(image_bytes)
+        subprocess.check_call([REF_HARNESS, "stb", d + "/i.img", d + "/o.bin"])
+        raw = open(d + "/o.bin", "rb").read()
+    w, h, c = struct.unpack_from("<iii", raw, 0)
+    return np.frombuffer(raw, np.uint8, w * h * c, 12).reshape(h, w, c).copy()

@@ -1,0 +1,644 @@
+// Device half of the C ABI: context, buffers, textures and the path-tracing pass.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "capi_common.h"
+#include "device/kernels.h"
+#include "host/accel_layout.h"
+#include "host/scene_types.h"
+
+using namespace rta;
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if(_e != hipSuccess) return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while(0)
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    uint64_t next_handle = 1;
+    std::unordered_map<uint64_t, pt_tex *> textures;
+};
+
+struct pt_buf {
+    pt_ctx *ctx = nullptr;
+    void *dptr = nullptr;
+    size_t bytes = 0;
+    std::vector<uint8_t> shadow;  // last bytes uploaded from the host, if shadow_valid
+    bool shadow_valid = false;
+    uint64_t version = 0;  // bumped by every content change
+};
+
+struct pt_tex {
+    pt_ctx *ctx = nullptr;
+    void *dptr = nullptr;
+    int width = 0, height = 0, channels = 0, format = 0;
+    uint64_t handle = 0;
+};
+
+namespace {
+
+constexpr int MAX_PATH_DEPTH = 64;
+constexpr int CNT_QUEUE = 0;       // [0, 70): paths alive per vertex
+constexpr int CNT_SHADOW = 70;     // [70, 140): paths with pending light samples per vertex
+constexpr int CNT_NEXT = 140;      // [140, 280): next-ray counters, two per vertex
+constexpr int CNT_INTERSECT = 280;
+constexpr int CNT_TOTAL = 288;
+
+struct DeviceArray {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if(need <= bytes && p) return PT_OK;
+        if(p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need ? need : 16);
+        if(e != hipSuccess) return fail(PT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        bytes = need ? need : 16;
+        return PT_OK;
+    }
+    void release() {
+        if(p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+const int OUT_SLOTS[7] = {PT_OUT_ALBEDO, PT_OUT_MOTION, PT_OUT_DEPTH, PT_OUT_NORMAL,
+                          PT_OUT_INSTANCE_INDEX, PT_OUT_DIRECT_LUM, PT_OUT_INDIRECT_LUM};
+const int OUT_CHANNELS[7] = {3, 2, 1, 3, 1, 3, 3};
+
+}  // namespace
+
+struct pt_pass {
+    pt_ctx *ctx = nullptr;
+    int W = 0, H = 0;
+    pt_buf *outputs[7] = {};
+    pt_buf *slots[7] = {};
+    uint64_t seen_version[7] = {};
+    const pt_buf *seen_ptr[7] = {};
+    pt_tex *sky = nullptr, *sky_cache = nullptr;
+    pt_params params;
+    bool have_params = false;
+    // derived scene
+    bool accel_valid = false;
+    AccelHost accel_info;  // header + sizes (vectors are cleared after upload)
+    DeviceArray d_mesh_nodes, d_scene_nodes, d_tri_pos, d_inst, d_spill, d_tex_table;
+    int n_textures = 0;
+    int spill_depth = 0;
+    size_t n_material_floats = 0;
+    // path state
+    DeviceArray d_rays, d_hits, d_thr, d_acc, d_shadow, d_queue_a, d_queue_b, d_queue_s, d_counters, d_stats, d_err;
+    int shadow_capacity = 0;
+    int trace_blocks = 0;
+};
+
+namespace {
+
+int download_shadow(pt_buf *b, std::vector<uint8_t> &out) {
+    if(b->shadow_valid) {
+        out = b->shadow;
+        return PT_OK;
+    }
+    out.resize(b->bytes);
+    if(b->bytes) {
+        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        HIP_TRY(hipMemcpy(out.data(), b->dptr, b->bytes, hipMemcpyDeviceToHost));
+    }
+    return PT_OK;
+}
+
+int upload_array(pt_ctx *ctx, DeviceArray &d, const void *src, size_t bytes) {
+    int rc = d.ensure(bytes);
+    if(rc) return rc;
+    if(bytes) {
+        HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return PT_OK;
+}
+
+bool slot_changed(pt_pass *p, int s) {
+    return p->seen_ptr[s] != p->slots[s] || (p->slots[s] && p->seen_version[s] != p->slots[s]->version);
+}
+void slot_mark(pt_pass *p, int s) {
+    p->seen_ptr[s] = p->slots[s];
+    p->seen_version[s] = p->slots[s] ? p->slots[s]->version : 0;
+}
+
+// (Re)builds whatever the bound scene buffers changed: traversal layout from slots 2-5,
+// texture descriptor table from slot 0, and validates material pointers against slot 1.
+int prepare_scene(pt_pass *p) {
+    pt_ctx *ctx = p->ctx;
+    for(int s = PT_SLOT_MATERIAL; s <= PT_SLOT_SCENE_BVH; s++)
+        if(!p->slots[s] || p->slots[s]->bytes == 0)
+            return fail(PT_ERR_STATE, "scene slot " + std::to_string(s) + " is not bound or empty");
+
+    const bool geo_changed = !p->accel_valid || slot_changed(p, PT_SLOT_TRIANGLE) || slot_changed(p, PT_SLOT_INSTANCE_INFO) ||
+                             slot_changed(p, PT_SLOT_MESH_BVH) || slot_changed(p, PT_SLOT_SCENE_BVH);
+    const bool mat_changed = slot_changed(p, PT_SLOT_MATERIAL);
+    if(geo_changed || mat_changed) {
+        std::vector<uint8_t> tris, inst, mesh, scene, mats;
+        int rc;
+        if((rc = download_shadow(p->slots[PT_SLOT_INSTANCE_INFO], inst))) return rc;
+        if((rc = download_shadow(p->slots[PT_SLOT_MATERIAL], mats))) return rc;
+        if(inst.size() % sizeof(InstanceInfo)) return fail(PT_ERR_INVALID, "instance buffer size is not a multiple of 112");
+        if(mats.size() % 4) return fail(PT_ERR_INVALID, "material buffer size is not a multiple of 4");
+        const size_t n_inst = inst.size() / sizeof(InstanceInfo), n_mat = mats.size() / 4;
+        const InstanceInfo *ii = reinterpret_cast<const InstanceInfo *>(inst.data());
+        const float *mf = reinterpret_cast<const float *>(mats.data());
+        for(size_t i = 0; i < n_inst; i++) {
+            const int mp = ii[i].materialPtr;
+            if(mp < 0 || (size_t)mp + 7 > n_mat) return fail(PT_ERR_INVALID, "instance " + std::to_string(i) + ": material pointer outside the material buffer");
+            if((int)(mf[mp] + 0.5f) == 2 && (size_t)mp + 8 > n_mat) return fail(PT_ERR_INVALID, "instance " + std::to_string(i) + ": dielectric record is truncated");
+        }
+        p->n_material_floats = n_mat;
+        if(geo_changed) {
+            if((rc = download_shadow(p->slots[PT_SLOT_TRIANGLE], tris))) return rc;
+            if((rc = download_shadow(p->slots[PT_SLOT_MESH_BVH], mesh))) return rc;
+            if((rc = download_shadow(p->slots[PT_SLOT_SCENE_BVH], scene))) return rc;
+            if(tris.size() % sizeof(TriangleRec) || mesh.size() % sizeof(BVHNodeInfo) || scene.size() % sizeof(BVHNodeInfo))
+                return fail(PT_ERR_INVALID, "triangle / BVH buffer sizes are not multiples of 96 / 48 bytes");
+            AccelHost ah;
+            std::string err;
+            if(!build_accel(reinterpret_cast<const BVHNodeInfo *>(mesh.data()), mesh.size() / sizeof(BVHNodeInfo),
+                            reinterpret_cast<const BVHNodeInfo *>(scene.data()), scene.size() / sizeof(BVHNodeInfo),
+                            reinterpret_cast<const TriangleRec *>(tris.data()), tris.size() / sizeof(TriangleRec), ii,
+                            n_inst, ah, err))
+                return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
+            if((rc = upload_array(ctx, p->d_mesh_nodes, ah.mesh_nodes.data(), ah.mesh_nodes.size() * sizeof(TNode)))) return rc;
+            if((rc = upload_array(ctx, p->d_scene_nodes, ah.scene_nodes.data(), ah.scene_nodes.size() * sizeof(TNode)))) return rc;
+            if((rc = upload_array(ctx, p->d_tri_pos, ah.tri_pos.data(), ah.tri_pos.size() * sizeof(TriPos)))) return rc;
+            if((rc = upload_array(ctx, p->d_inst, ah.instances.data(), ah.instances.size() * sizeof(InstAccel)))) return rc;
+            p->accel_info.header = ah.header;
+            p->accel_info.max_stack = ah.max_stack;
+            int need = ah.max_stack + 2 - LDS_STACK;
+            if(need < 0) need = 0;
+            if(need > p->spill_depth || !p->d_spill.p) {
+                p->spill_depth = need < 4 ? 4 : need;
+                const size_t nthreads = (size_t)p->trace_blocks * TRACE_BLOCK;
+                if((rc = p->d_spill.ensure(nthreads * (size_t)p->spill_depth * sizeof(uint2)))) return rc;
+            }
+            p->accel_valid = true;
+            slot_mark(p, PT_SLOT_TRIANGLE);
+            slot_mark(p, PT_SLOT_MESH_BVH);
+            slot_mark(p, PT_SLOT_SCENE_BVH);
+        }
+        slot_mark(p, PT_SLOT_INSTANCE_INFO);
+        slot_mark(p, PT_SLOT_MATERIAL);
+    }
+    if(slot_changed(p, PT_SLOT_TEXTURE_HANDLES) || !p->d_tex_table.p) {
+        std::vector<TexDesc> table;
+        pt_buf *hb = p->slots[PT_SLOT_TEXTURE_HANDLES];
+        if(hb && hb->bytes) {
+            std::vector<uint8_t> raw;
+            int rc = download_shadow(hb, raw);
+            if(rc) return rc;
+            if(raw.size() % 8) return fail(PT_ERR_INVALID, "texture handle buffer size is not a multiple of 8");
+            const uint64_t *h = reinterpret_cast<const uint64_t *>(raw.data());
+            for(size_t k = 0; k < raw.size() / 8; k++) {
+                auto it = ctx->textures.find(h[k]);
+                if(it == ctx->textures.end()) return fail(PT_ERR_INVALID, "texture handle " + std::to_string(k) + " does not name a live texture of this context");
+                TexDesc d;
+                d.data = it->second->dptr;
+                d.width = it->second->width; d.height = it->second->height;
+                d.channels = it->second->channels; d.format = it->second->format;
+                table.push_back(d);
+            }
+        }
+        p->n_textures = (int)table.size();
+        TexDesc dummy;
+        memset(&dummy, 0, sizeof dummy);
+        int rc = upload_array(ctx, p->d_tex_table, table.empty() ? &dummy : table.data(),
+                              (table.empty() ? 1 : table.size()) * sizeof(TexDesc));
+        if(rc) return rc;
+        slot_mark(p, PT_SLOT_TEXTURE_HANDLES);
+    }
+    return PT_OK;
+}
+
+TraceScene make_trace_scene(pt_pass *p) {
+    TraceScene sc;
+    sc.mesh_nodes = static_cast<const TNode *>(p->d_mesh_nodes.p);
+    sc.scene_nodes = static_cast<const TNode *>(p->d_scene_nodes.p);
+    sc.tri_pos = static_cast<const TriPos *>(p->d_tri_pos.p);
+    sc.inst = static_cast<const InstAccel *>(p->d_inst.p);
+    sc.hdr = p->accel_info.header;
+    sc.spill = static_cast<uint2 *>(p->d_spill.p);
+    sc.spill_depth = p->spill_depth;
+    sc.error_flag = static_cast<unsigned *>(p->d_err.p);
+    return sc;
+}
+
+TexDesc desc_of(const pt_tex *t) {
+    TexDesc d;
+    d.data = t->dptr;
+    d.width = t->width; d.height = t->height; d.channels = t->channels; d.format = t->format;
+    return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------- context
+int pt_ctx_create(int device_id, pt_ctx **out) {
+    if(!out) return fail(PT_ERR_INVALID, "pt_ctx_create: out is null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if(device_id < 0 || device_id >= n) return fail(PT_ERR_INVALID, "pt_ctx_create: no such device " + std::to_string(device_id) + " (" + std::to_string(n) + " visible)");
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if(std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(PT_ERR_UNSUPPORTED, std::string("pt_ctx_create: this library is built for gfx950 only, device is ") + prop.gcnArchName);
+    pt_ctx *c = new pt_ctx;
+    c->device = device_id;
+    c->num_cus = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if(e != hipSuccess) {
+        delete c;
+        return fail(PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return PT_OK;
+}
+
+int pt_ctx_destroy(pt_ctx *ctx) {
+    if(!ctx) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PT_OK;
+}
+
+int pt_ctx_synchronize(pt_ctx *ctx) {
+    if(!ctx) return fail(PT_ERR_INVALID, "pt_ctx_synchronize: null context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+void *pt_ctx_stream(pt_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ------------------------------------------------------------------------------- buffers
+int pt_buf_create(pt_ctx *ctx, size_t bytes, const void *host, pt_buf **out) {
+    if(!ctx || !out) return fail(PT_ERR_INVALID, "pt_buf_create: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    pt_buf *b = new pt_buf;
+    b->ctx = ctx;
+    b->bytes = bytes;
+    hipError_t e = hipMalloc(&b->dptr, bytes ? bytes : 16);
+    if(e != hipSuccess) {
+        delete b;
+        return fail(PT_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    }
+    *out = b;
+    if(host && bytes) {
+        int rc = pt_buf_upload(b, host, bytes);
+        if(rc) {
+            (void)hipFree(b->dptr);
+            delete b;
+            *out = nullptr;
+            return rc;
+        }
+    }
+    return PT_OK;
+}
+
+int pt_buf_release(pt_buf *buf) {
+    if(!buf) return PT_OK;
+    (void)hipSetDevice(buf->ctx->device);
+    (void)hipStreamSynchronize(buf->ctx->stream);
+    if(buf->dptr) (void)hipFree(buf->dptr);
+    delete buf;
+    return PT_OK;
+}
+
+int pt_buf_upload(pt_buf *buf, const void *host, size_t bytes) {
+    if(!buf || (!host && bytes)) return fail(PT_ERR_INVALID, "pt_buf_upload: null argument");
+    if(bytes != buf->bytes) return fail(PT_ERR_INVALID, "pt_buf_upload: size " + std::to_string(bytes) + " does not match buffer size " + std::to_string(buf->bytes));
+    HIP_TRY(hipSetDevice(buf->ctx->device));
+    buf->version++;
+    if(!bytes) return PT_OK;
+    buf->shadow.assign(static_cast<const uint8_t *>(host), static_cast<const uint8_t *>(host) + bytes);
+    buf->shadow_valid = true;
+    HIP_TRY(hipMemcpyAsync(buf->dptr, buf->shadow.data(), bytes, hipMemcpyHostToDevice, buf->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(buf->ctx->stream));
+    return PT_OK;
+}
+
+int pt_buf_copy(pt_buf *dst, const pt_buf *src) {
+    if(!dst || !src) return fail(PT_ERR_INVALID, "pt_buf_copy: null argument");
+    if(dst->bytes != src->bytes) return fail(PT_ERR_INVALID, "pt_buf_copy: sizes differ");
+    if(dst->ctx != src->ctx) return fail(PT_ERR_INVALID, "pt_buf_copy: buffers belong to different contexts");
+    HIP_TRY(hipSetDevice(dst->ctx->device));
+    dst->version++;
+    dst->shadow_valid = src->shadow_valid;
+    if(src->shadow_valid) dst->shadow = src->shadow;
+    if(dst->bytes) HIP_TRY(hipMemcpyAsync(dst->dptr, src->dptr, dst->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
+    return PT_OK;
+}
+
+int pt_buf_fill(pt_buf *buf, const void *elem, size_t elem_bytes) {
+    if(!buf || !elem) return fail(PT_ERR_INVALID, "pt_buf_fill: null argument");
+    if(elem_bytes == 0 || buf->bytes % elem_bytes) return fail(PT_ERR_INVALID, "pt_buf_fill: buffer size is not a multiple of the element size");
+    HIP_TRY(hipSetDevice(buf->ctx->device));
+    buf->version++;
+    buf->shadow_valid = false;
+    buf->shadow.clear();
+    if(!buf->bytes) return PT_OK;
+    if(elem_bytes == 4) {
+        uint32_t v;
+        memcpy(&v, elem, 4);
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)buf->dptr, (int)v, buf->bytes / 4, buf->ctx->stream));
+        return PT_OK;
+    }
+    if(elem_bytes == 1) {
+        HIP_TRY(hipMemsetAsync(buf->dptr, *static_cast<const uint8_t *>(elem), buf->bytes, buf->ctx->stream));
+        return PT_OK;
+    }
+    // other widths: replicate on the host, as the reference's fill does (SSBOBuffer.h:75)
+    std::vector<uint8_t> tmp(buf->bytes);
+    for(size_t o = 0; o < buf->bytes; o += elem_bytes) memcpy(tmp.data() + o, elem, elem_bytes);
+    HIP_TRY(hipMemcpyAsync(buf->dptr, tmp.data(), buf->bytes, hipMemcpyHostToDevice, buf->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(buf->ctx->stream));
+    return PT_OK;
+}
+
+int pt_buf_download(const pt_buf *buf, void *host, size_t bytes) {
+    if(!buf || (!host && bytes)) return fail(PT_ERR_INVALID, "pt_buf_download: null argument");
+    if(bytes > buf->bytes) return fail(PT_ERR_INVALID, "pt_buf_download: more bytes requested than the buffer holds");
+    HIP_TRY(hipSetDevice(buf->ctx->device));
+    HIP_TRY(hipStreamSynchronize(buf->ctx->stream));
+    if(bytes) HIP_TRY(hipMemcpy(host, buf->dptr, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+size_t pt_buf_bytes(const pt_buf *buf) { return buf ? buf->bytes : 0; }
+void *pt_buf_device_ptr(const pt_buf *buf) { return buf ? buf->dptr : nullptr; }
+
+// ------------------------------------------------------------------------------- textures
+int pt_tex_create(pt_ctx *ctx, int width, int height, int channels, int format, const void *data, pt_tex **out) {
+    if(!ctx || !out || !data) return fail(PT_ERR_INVALID, "pt_tex_create: null argument");
+    if(width <= 0 || height <= 0 || (channels != 1 && channels != 3 && channels != 4))
+        return fail(PT_ERR_INVALID, "pt_tex_create: width/height must be positive and channels 1, 3 or 4");
+    if(format != PT_TEX_U8 && format != PT_TEX_F32) return fail(PT_ERR_INVALID, "pt_tex_create: unknown format");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)width * height * channels * (format == PT_TEX_F32 ? 4 : 1);
+    pt_tex *t = new pt_tex;
+    t->ctx = ctx;
+    t->width = width; t->height = height; t->channels = channels; t->format = format;
+    hipError_t e = hipMalloc(&t->dptr, bytes);
+    if(e == hipSuccess) e = hipMemcpyAsync(t->dptr, data, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if(e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if(e != hipSuccess) {
+        if(t->dptr) (void)hipFree(t->dptr);
+        delete t;
+        return fail(PT_ERR_HIP, std::string("pt_tex_create: ") + hipGetErrorString(e));
+    }
+    t->handle = ctx->next_handle++;
+    ctx->textures[t->handle] = t;
+    *out = t;
+    return PT_OK;
+}
+
+int pt_tex_release(pt_tex *tex) {
+    if(!tex) return PT_OK;
+    (void)hipSetDevice(tex->ctx->device);
+    (void)hipStreamSynchronize(tex->ctx->stream);
+    tex->ctx->textures.erase(tex->handle);
+    if(tex->dptr) (void)hipFree(tex->dptr);
+    delete tex;
+    return PT_OK;
+}
+
+uint64_t pt_tex_handle(const pt_tex *tex) { return tex ? tex->handle : 0; }
+
+// ------------------------------------------------------------------------------- pass
+int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
+    if(!ctx || !out) return fail(PT_ERR_INVALID, "pt_pass_create: null argument");
+    if(screen_w <= 0 || screen_h <= 0 || (long long)screen_w * screen_h > (1ll << 28))
+        return fail(PT_ERR_INVALID, "pt_pass_create: unsupported resolution");
+    HIP_TRY(hipSetDevice(ctx->device));
+    pt_pass *p = new pt_pass;
+    p->ctx = ctx;
+    p->W = screen_w;
+    p->H = screen_h;
+    memset(&p->params, 0, sizeof p->params);
+    const size_t npix = (size_t)screen_w * screen_h;
+    int rc = PT_OK;
+    for(int k = 0; k < 7 && !rc; k++) rc = pt_buf_create(ctx, npix * OUT_CHANNELS[k] * sizeof(float), nullptr, &p->outputs[k]);
+    // 6 blocks of 256 threads per CU: 24 KiB of LDS stack each, 24 waves per CU
+    p->trace_blocks = ctx->num_cus * 6;
+    if(!rc) rc = p->d_rays.ensure(npix * sizeof(PathRay));
+    if(!rc) rc = p->d_hits.ensure(npix * sizeof(PathHit));
+    if(!rc) rc = p->d_thr.ensure(npix * sizeof(PathThroughput));
+    if(!rc) rc = p->d_acc.ensure(npix * sizeof(PathAccum));
+    if(!rc) rc = p->d_queue_a.ensure(npix * 4);
+    if(!rc) rc = p->d_queue_b.ensure(npix * 4);
+    if(!rc) rc = p->d_queue_s.ensure(npix * 4);
+    if(!rc) rc = p->d_counters.ensure(CNT_TOTAL * 4);
+    if(!rc) rc = p->d_stats.ensure(8 * 8);
+    if(!rc) rc = p->d_err.ensure(16);
+    if(!rc) {
+        hipError_t e = hipMemsetAsync(p->d_stats.p, 0, 64, ctx->stream);
+        if(e == hipSuccess) e = hipMemsetAsync(p->d_err.p, 0, 16, ctx->stream);
+        if(e == hipSuccess) e = hipMemsetAsync(p->d_counters.p, 0, CNT_TOTAL * 4, ctx->stream);
+        if(e != hipSuccess) rc = fail(PT_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    }
+    if(rc) {
+        pt_pass_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return PT_OK;
+}
+
+int pt_pass_destroy(pt_pass *p) {
+    if(!p) return PT_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for(int k = 0; k < 7; k++) pt_buf_release(p->outputs[k]);
+    DeviceArray *arrs[] = {&p->d_mesh_nodes, &p->d_scene_nodes, &p->d_tri_pos, &p->d_inst, &p->d_spill, &p->d_tex_table,
+                           &p->d_rays, &p->d_hits, &p->d_thr, &p->d_acc, &p->d_shadow, &p->d_queue_a, &p->d_queue_b,
+                           &p->d_queue_s, &p->d_counters, &p->d_stats, &p->d_err};
+    for(DeviceArray *a : arrs) a->release();
+    delete p;
+    return PT_OK;
+}
+
+int pt_pass_bind(pt_pass *pass, int slot, pt_buf *buf) {
+    if(!pass) return fail(PT_ERR_INVALID, "pt_pass_bind: null pass");
+    if(slot < 0 || slot > 6) return fail(PT_ERR_INVALID, "pt_pass_bind: slot must be 0..6");
+    if(buf && buf->ctx != pass->ctx) return fail(PT_ERR_INVALID, "pt_pass_bind: buffer belongs to another context");
+    pass->slots[slot] = buf;
+    return PT_OK;
+}
+
+int pt_pass_bind_texture(pt_pass *pass, const char *name, pt_tex *tex) {
+    if(!pass || !name) return fail(PT_ERR_INVALID, "pt_pass_bind_texture: null argument");
+    if(tex && tex->ctx != pass->ctx) return fail(PT_ERR_INVALID, "pt_pass_bind_texture: texture belongs to another context");
+    if(tex && (tex->format != PT_TEX_F32 || tex->channels != 3))
+        return fail(PT_ERR_INVALID, "pt_pass_bind_texture: sky textures must be 3-channel float");
+    if(!strcmp(name, "skybox")) pass->sky = tex;
+    else if(!strcmp(name, "skybox_samplecache")) pass->sky_cache = tex;
+    else return fail(PT_ERR_INVALID, std::string("pt_pass_bind_texture: unknown sampler name ") + name);
+    return PT_OK;
+}
+
+int pt_pass_set_params(pt_pass *pass, const pt_params *params) {
+    if(!pass || !params) return fail(PT_ERR_INVALID, "pt_pass_set_params: null argument");
+    if(params->SCREEN_W != pass->W || params->SCREEN_H != pass->H)
+        return fail(PT_ERR_INVALID, "pt_pass_set_params: SCREEN_W/H differ from the size the pass was created with");
+    if(params->MAX_DEPTH < 0 || params->MAX_DEPTH > MAX_PATH_DEPTH)
+        return fail(PT_ERR_INVALID, "pt_pass_set_params: MAX_DEPTH must be 0.." + std::to_string(MAX_PATH_DEPTH));
+    if(params->lightCount < 0) return fail(PT_ERR_INVALID, "pt_pass_set_params: negative lightCount");
+    if(params->accum_mode != 0 && params->accum_mode != 1) return fail(PT_ERR_INVALID, "pt_pass_set_params: accum_mode must be 0 or 1");
+    if(params->RasterizaionFor1st)
+        return fail(PT_ERR_UNSUPPORTED, "pt_pass_set_params: RasterizaionFor1st needs the raster G-buffer inputs, which this pass does not take; primary rays are traced");
+    pass->params = *params;
+    pass->have_params = true;
+    return PT_OK;
+}
+
+int pt_pass_draw(pt_pass *p) {
+    if(!p) return fail(PT_ERR_INVALID, "pt_pass_draw: null pass");
+    if(!p->have_params) return fail(PT_ERR_STATE, "pt_pass_draw: pt_pass_set_params has not been called");
+    pt_ctx *ctx = p->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = prepare_scene(p);
+    if(rc) return rc;
+    const pt_params &P = p->params;
+    if(!p->sky) return fail(PT_ERR_STATE, "pt_pass_draw: texture \"skybox\" is not bound");
+    if(P.SkyboxLighting && P.SkyboxSampling && !p->sky_cache)
+        return fail(PT_ERR_STATE, "pt_pass_draw: texture \"skybox_samplecache\" is not bound");
+    if(P.SKY_W <= 0 || P.SKY_H <= 0) return fail(PT_ERR_INVALID, "pt_pass_draw: SKY_W / SKY_H must be positive");
+    if(P.lightCount > 0) {
+        pt_buf *lb = p->slots[PT_SLOT_LIGHT];
+        if(!lb || lb->bytes < (size_t)P.lightCount * sizeof(LightInfo))
+            return fail(PT_ERR_STATE, "pt_pass_draw: lightCount exceeds the bound light buffer");
+    }
+    const size_t npix = (size_t)p->W * p->H;
+    const int n_shadow = 1 + P.lightCount;
+    if(n_shadow > p->shadow_capacity) {
+        if((rc = p->d_shadow.ensure(npix * n_shadow * sizeof(ShadowEntry)))) return rc;
+        p->shadow_capacity = n_shadow;
+    }
+
+    DrawParams dp;
+    memset(&dp, 0, sizeof dp);
+    dp.p = P;
+    dp.W = p->W; dp.H = p->H; dp.npix = (int)npix;
+    dp.n_shadow = n_shadow;
+    dp.materials = static_cast<const float *>(p->slots[PT_SLOT_MATERIAL]->dptr);
+    dp.n_material_floats = (int)p->n_material_floats;
+    dp.tris = static_cast<const TriangleRec *>(p->slots[PT_SLOT_TRIANGLE]->dptr);
+    dp.inst = static_cast<const InstAccel *>(p->d_inst.p);
+    dp.lights = p->slots[PT_SLOT_LIGHT] ? static_cast<const LightInfo *>(p->slots[PT_SLOT_LIGHT]->dptr) : nullptr;
+    dp.textures = static_cast<const TexDesc *>(p->d_tex_table.p);
+    dp.n_textures = p->n_textures;
+    dp.sky = desc_of(p->sky);
+    dp.sky_cache = p->sky_cache ? desc_of(p->sky_cache) : desc_of(p->sky);
+    dp.rays = static_cast<PathRay *>(p->d_rays.p);
+    dp.hits = static_cast<PathHit *>(p->d_hits.p);
+    dp.thr = static_cast<PathThroughput *>(p->d_thr.p);
+    dp.acc = static_cast<PathAccum *>(p->d_acc.p);
+    dp.shadow = static_cast<ShadowEntry *>(p->d_shadow.p);
+    float *outs[7];
+    for(int k = 0; k < 7; k++) {
+        outs[k] = static_cast<float *>(p->outputs[k]->dptr);
+        p->outputs[k]->version++;
+        p->outputs[k]->shadow_valid = false;
+    }
+    dp.o_albedo = outs[0]; dp.o_motion = outs[1]; dp.o_depth = outs[2]; dp.o_normal = outs[3];
+    dp.o_inst = outs[4]; dp.o_direct = outs[5]; dp.o_indirect = outs[6];
+    dp.stats = static_cast<unsigned long long *>(p->d_stats.p);
+    unsigned *cnt = static_cast<unsigned *>(p->d_counters.p);
+    dp.counters = cnt;
+
+    hipStream_t s = ctx->stream;
+    const TraceScene sc = make_trace_scene(p);
+    HIP_TRY(hipMemsetAsync(cnt, 0, CNT_TOTAL * 4, s));
+    launch_generate(s, dp);
+    unsigned *qa = static_cast<unsigned *>(p->d_queue_a.p), *qb = static_cast<unsigned *>(p->d_queue_b.p);
+    unsigned *qs = static_cast<unsigned *>(p->d_queue_s.p);
+    const unsigned *q_in = nullptr;  // vertex 0: every pixel, in pixel order
+    for(int dep = 0; dep <= P.MAX_DEPTH; dep++) {
+        unsigned *q_out = (dep & 1) ? qb : qa;
+        launch_extend(s, sc, p->trace_blocks, q_in, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
+        launch_shade(s, dp, dep, q_in, cnt + CNT_QUEUE + dep, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep);
+        if(dep < P.MAX_DEPTH) {
+            launch_shadow(s, sc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
+                          cnt + CNT_NEXT + 2 * dep + 1);
+            launch_shadow_apply(s, dp, qs, cnt + CNT_SHADOW + dep);
+        }
+        q_in = q_out;
+    }
+    launch_finalize(s, dp);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_pass_output(pt_pass *pass, int which, pt_buf **out) {
+    if(!pass || !out) return fail(PT_ERR_INVALID, "pt_pass_output: null argument");
+    for(int k = 0; k < 7; k++)
+        if(OUT_SLOTS[k] == which) {
+            *out = pass->outputs[k];
+            return PT_OK;
+        }
+    return fail(PT_ERR_INVALID, "pt_pass_output: unknown output " + std::to_string(which));
+}
+
+int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
+    if(!pass || !out) return fail(PT_ERR_INVALID, "pt_pass_stats: null argument");
+    HIP_TRY(hipSetDevice(pass->ctx->device));
+    HIP_TRY(hipStreamSynchronize(pass->ctx->stream));
+    unsigned long long raw[8];
+    unsigned err = 0;
+    HIP_TRY(hipMemcpy(raw, pass->d_stats.p, sizeof raw, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&err, pass->d_err.p, 4, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->samples = raw[0];
+    out->rays_extend = raw[1];
+    out->rays_shadow = raw[2];
+    out->draws = raw[3];
+    if(reset) HIP_TRY(hipMemsetAsync(pass->d_stats.p, 0, 64, pass->ctx->stream));
+    if(err) {
+        HIP_TRY(hipMemsetAsync(pass->d_err.p, 0, 16, pass->ctx->stream));
+        return fail(PT_ERR_STATE, "traversal stack overflow: a ray needed more deferred nodes than the tree height allows; results of the last calls are incomplete");
+    }
+    return PT_OK;
+}
+
+int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
+    if(!p || !rays || !hits) return fail(PT_ERR_INVALID, "pt_pass_intersect: null argument");
+    if(rays->ctx != p->ctx || hits->ctx != p->ctx) return fail(PT_ERR_INVALID, "pt_pass_intersect: buffers belong to another context");
+    if(n > 0xFFFFFF00ull) return fail(PT_ERR_INVALID, "pt_pass_intersect: too many rays for one call");
+    if(rays->bytes < n * 6 * sizeof(float)) return fail(PT_ERR_INVALID, "pt_pass_intersect: ray buffer holds fewer than n rays");
+    if(hits->bytes < n * sizeof(pt_hit)) return fail(PT_ERR_INVALID, "pt_pass_intersect: hit buffer holds fewer than n records");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    int rc = prepare_scene(p);
+    if(rc) return rc;
+    hits->version++;
+    hits->shadow_valid = false;
+    if(n == 0) return PT_OK;
+    unsigned *cnt = static_cast<unsigned *>(p->d_counters.p);
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemsetAsync(cnt + CNT_INTERSECT, 0, 4, s));
+    const TraceScene sc = make_trace_scene(p);
+    long long blocks = ((long long)n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    if(blocks > p->trace_blocks) blocks = p->trace_blocks;
+    launch_intersect(s, sc, (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n,
+                     static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+}  // extern "C"

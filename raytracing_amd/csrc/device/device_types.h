@@ -1,0 +1,117 @@
+// Records shared by the host re-layout code and the HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace rta {
+
+// ---- traversal layout ---------------------------------------------------------------
+// The reference's 48-byte node holds its OWN box and two child indices, so visiting a
+// node costs one dependent fetch per child before anything can be culled.  Here an
+// inner node carries the boxes of BOTH children in one 64-byte, 64-byte-aligned record
+// (half a 128-byte L2 line, four 16-byte loads per lane), and a child that is a leaf is
+// referenced directly, so leaves need no node fetch at all.
+//
+// Child reference: bits 31..30 = kind, bits 29..0 = index.
+enum : uint32_t {
+    REF_MESH_INNER = 0u,   // index into the mesh TNode array
+    REF_TRIANGLE = 1u,     // index into the triangle arrays
+    REF_SCENE_INNER = 2u,  // index into the scene TNode array
+    REF_INSTANCE = 3u,     // index into the instance array
+    REF_INDEX_MASK = 0x3FFFFFFFu
+};
+inline uint32_t make_ref(uint32_t kind, uint32_t index) { return (kind << 30) | index; }
+
+struct alignas(64) TNode {
+    float lo0[3], hi0[3];  // box of child 0 (the reference's ls)
+    float lo1[3], hi1[3];  // box of child 1 (the reference's rs)
+    uint32_t c0, c1;       // child references
+    uint32_t pad[2];
+};
+static_assert(sizeof(TNode) == 64, "traversal node is 64 bytes");
+
+// Vertex 0 and the two edges (v1 - v0, v2 - v0) of a triangle, 48 bytes, 16-byte aligned.
+// The edges are the same fp32 differences the intersection routine would form itself.
+struct alignas(16) TriPos {
+    float v0[3];
+    float e1[3];
+    float e2[3];
+    float pad[3];
+};
+static_assert(sizeof(TriPos) == 48, "triangle position record is 48 bytes");
+
+// Per-instance record, 96 bytes.  row[r] = (m[0][r], m[1][r], m[2][r], m[3][r]) of the
+// column-major world-to-local matrix, i.e. local = row . (world, 1).
+struct alignas(16) InstAccel {
+    float row[3][4];
+    float root_lo[3], root_hi[3];  // box of the mesh root (tested in local space)
+    uint32_t root_ref;             // mesh root: inner node or, for a 1-triangle mesh, the triangle
+    int32_t material_ptr;
+    uint32_t pad[4];
+};
+static_assert(sizeof(InstAccel) == 96, "instance record is 96 bytes");
+
+struct SceneHeader {
+    float root_lo[3], root_hi[3];  // box of scene node 0
+    uint32_t root_ref;             // scene inner node 0, or the only instance
+    uint32_t n_instances;
+};
+
+// ---- closest-hit record (matches pt_hit in the public header, padded to 32 B in the
+//      path-state arrays) ---------------------------------------------------------------
+struct HitRec {
+    int32_t instance;
+    int32_t triangle;
+    float t, u, v;
+};
+
+struct alignas(16) PathHit {
+    float t, u, v;
+    int32_t triangle;
+    int32_t instance;
+    int32_t pad[3];
+};
+static_assert(sizeof(PathHit) == 32, "path hit record is 32 bytes");
+
+struct alignas(16) PathRay {
+    float o[3];
+    float tmax2;  // shadow rays towards point lights: squared distance limit; unused otherwise
+    float d[3];
+    uint32_t flags;
+};
+static_assert(sizeof(PathRay) == 32, "path ray record is 32 bytes");
+
+// throughput, pending BSDF-sample weight and sampler state of one path
+struct alignas(16) PathThroughput {
+    float history[3];
+    float pdf;        // pdf of the BSDF-sampled direction the current ray follows
+    float weight[3];  // fr * |cos| of that sample
+    uint32_t dim;     // next Sobol dimension
+};
+static_assert(sizeof(PathThroughput) == 32, "path throughput record is 32 bytes");
+
+struct alignas(16) PathAccum {
+    float di[3];
+    float first_exist;  // 1 when the primary ray hit something
+    float gi[3];
+    float pad0;
+    float albedo[3];
+    float pad1;
+};
+static_assert(sizeof(PathAccum) == 48, "path accumulator record is 48 bytes");
+
+// One pending light sample (sky NEE or an analytic light) of one path vertex.
+struct alignas(16) ShadowEntry {
+    float d[3];
+    float dis2;      // occluders beyond sqrt(dis2) do not count (1e18 for sky / directional)
+    float recv[3];   // radiance * fr * |cos| / pdf, before the path throughput
+    uint32_t flags;  // bit0 valid, bit1 path vertex is the first one (also sets direct light),
+                     // bit2 visible (written by the shadow stage)
+};
+static_assert(sizeof(ShadowEntry) == 32, "shadow entry is 32 bytes");
+
+struct TexDesc {
+    const void *data;
+    int32_t width, height, channels, format;  // format 0 = u8 unorm, 1 = f32
+};
+
+}  // namespace rta

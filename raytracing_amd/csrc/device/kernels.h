@@ -1,0 +1,62 @@
+// Host-callable launchers of the HIP kernels (defined in the .hip files of this directory).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../../include/raytracing_amd.h"
+#include "../host/scene_types.h"
+#include "device_types.h"
+#include "trace_core.h"
+
+namespace rta {
+
+// Everything one draw needs, passed to the kernels by value.
+struct DrawParams {
+    pt_params p;
+    int W, H, npix;
+    int n_shadow;  // shadow entries per pixel = 1 (sky) + lightCount
+    // scene
+    const float *materials;
+    int n_material_floats;
+    const TriangleRec *tris;
+    const InstAccel *inst;
+    const LightInfo *lights;
+    const TexDesc *textures;
+    int n_textures;
+    TexDesc sky, sky_cache;
+    // path state, one slot per pixel
+    PathRay *rays;
+    PathHit *hits;
+    PathThroughput *thr;
+    PathAccum *acc;
+    ShadowEntry *shadow;  // [n_shadow][npix]
+    // outputs
+    float *o_direct, *o_indirect, *o_albedo, *o_motion, *o_depth, *o_normal, *o_inst;
+    // counters: [0] samples, [1] extend rays, [2] shadow rays, [3] draws
+    unsigned long long *stats;
+    // per-draw queue counters, zeroed before generate: [d] = paths alive at vertex d
+    unsigned *counters;
+};
+
+struct LaunchGeom {
+    int blocks;  // persistent trace grid
+};
+
+// closest hit for n rays given as 6 floats each; hits as pt_hit records
+void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n, pt_hit *hits,
+                      unsigned *next_counter);
+// extend stage: rays[queue[q]] -> hits[queue[q]] for q < *count (queue == nullptr: q itself)
+void launch_extend(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                   const PathRay *rays, PathHit *hits, unsigned *next_counter);
+// shadow stage: ray (q, k) for q < *count, k < n_shadow; marks visible entries
+void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                   const PathRay *rays, ShadowEntry *shadow, int n_shadow, int npix, unsigned *next_counter);
+
+void launch_generate(hipStream_t s, const DrawParams &dp);
+// shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to
+// queue_out and paths with pending light samples to shadow_queue.
+void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,
+                  unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count);
+void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,
+                         const unsigned *shadow_count);
+void launch_finalize(hipStream_t s, const DrawParams &dp);
+
+}  // namespace rta

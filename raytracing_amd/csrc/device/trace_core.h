@@ -1,0 +1,218 @@
+// Closest-hit / occlusion traversal of the two-level BVH, one ray per lane.
+//
+// Semantics are those of intersect_sceneBVH / intersect_meshBVH / intersect_aabb /
+// intersect_triangle in the reference's shader/pathtracing.glsl:208-316, reproduced
+// bit for bit in fp32:
+//   - the visiting order is the reference's (right child first, no near/far sorting),
+//   - a node is dropped when its box test fails or, at the moment it is taken off the
+//     stack, its entry distance exceeds the closest hit so far (tnear > t_best),
+//   - triangle leaves are tested without a box test of their own,
+//   - a triangle is accepted when 0.001 <= t, 0 <= u, 0 <= v, u + v <= 1 and t < t_best.
+// What differs is only how the work is laid out: both child boxes arrive with the parent
+// (one 64-byte fetch per inner node, none per leaf), the box tests therefore run when the
+// parent is visited and the entry distance travels with the deferred child on the stack;
+// the right child is continued with directly instead of being pushed and popped.
+//
+// No fused multiply-add may be formed in this file (compile with -ffp-contract=off):
+// the CPU checker evaluates the same expressions unfused.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.h"
+
+namespace rta {
+
+constexpr int TRACE_BLOCK = 256;
+constexpr int LDS_STACK = 12;  // deferred entries kept in LDS per lane (8 B each, 24 KiB per block)
+constexpr float RT_INF = 1e18f;
+constexpr float RT_RAY_MINDIS = 0.001f;
+
+struct TraceScene {
+    const TNode *mesh_nodes;
+    const TNode *scene_nodes;
+    const TriPos *tri_pos;
+    const InstAccel *inst;
+    SceneHeader hdr;
+    uint2 *spill;            // [spill_depth][total threads of the launch]
+    int spill_depth;
+    unsigned *error_flag;    // set to 1 when a ray needed more stack than LDS + spill
+};
+
+struct LaneHit {
+    float t, u, v;
+    int tri, inst;
+};
+
+// intersect_aabb, shader/pathtracing.glsl:208-221.  Division by the direction is IEEE
+// division (zero components give infinities / NaN exactly as they would there); min and
+// max drop a NaN operand.
+__device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float hix, float hiy, float hiz, float ox,
+                                          float oy, float oz, float dx, float dy, float dz, float &tnear) {
+    float t1x = (lox - ox) / dx, t1y = (loy - oy) / dy, t1z = (loz - oz) / dz;
+    float t2x = (hix - ox) / dx, t2y = (hiy - oy) / dy, t2z = (hiz - oz) / dz;
+    float tmi = fmaxf(0.0f, fminf(t1x, t2x));
+    tmi = fmaxf(tmi, fminf(t1y, t2y));
+    tmi = fmaxf(tmi, fminf(t1z, t2z));
+    float tmx = fminf(RT_INF, fmaxf(t1x, t2x));
+    tmx = fminf(tmx, fmaxf(t1y, t2y));
+    tmx = fminf(tmx, fmaxf(t1z, t2z));
+    tnear = tmi;
+    return tmx >= tmi && tmx >= RT_RAY_MINDIS;
+}
+
+// Persistent-wave traversal.  Every lane owns one ray at a time; a lane whose ray is
+// finished takes the next ray index from *next_ray (one atomic per lane, merged per wave
+// by the compiler) as soon as fewer than REFILL_BELOW lanes of its wave are still busy,
+// so long rays do not hold 63 idle lanes hostage.  Every wave leaves the loop once the
+// counter has passed n_rays and its own lanes are done.
+//
+// Source: bool load(unsigned idx, float o[3], float d[3], bool &any_hit)   false = no ray for idx
+// Sink:   void store(unsigned idx, const LaneHit &h)                        h.tri < 0 = miss
+template <class Source, class Sink>
+__device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &src, Sink &sink, unsigned *next_ray,
+                                                 unsigned n_rays, uint2 *s_stack) {
+    constexpr int REFILL_BELOW = 44;
+    const unsigned tid = threadIdx.x;
+    const unsigned gtid = blockIdx.x * blockDim.x + tid;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+
+    bool active = false, have = false, exhausted = false, any_hit = false;
+    unsigned ray_idx = 0;
+    int sp = 0;
+    float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;  // world-space ray
+    float lox = 0, loy = 0, loz = 0, ldx = 0, ldy = 0, ldz = 0;  // ray in the current instance's space
+    LaneHit best;
+    best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
+    int cur_inst = -1;
+    unsigned ref = 0;
+    float tn = 0;
+
+    for(;;) {
+        if(!active && !exhausted) {
+            unsigned idx = atomicAdd(next_ray, 1u);
+            if(idx < n_rays) {
+                float o[3], d[3];
+                bool ah = false;
+                if(src.load(idx, o, d, ah)) {
+                    ray_idx = idx;
+                    any_hit = ah;
+                    wox = o[0]; woy = o[1]; woz = o[2];
+                    wdx = d[0]; wdy = d[1]; wdz = d[2];
+                    best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
+                    active = true;
+                    sp = 0;
+                    float t0;
+                    have = slab_test(sc.hdr.root_lo[0], sc.hdr.root_lo[1], sc.hdr.root_lo[2], sc.hdr.root_hi[0],
+                                     sc.hdr.root_hi[1], sc.hdr.root_hi[2], wox, woy, woz, wdx, wdy, wdz, t0);
+                    ref = sc.hdr.root_ref;
+                    tn = t0;
+                }
+            } else {
+                exhausted = true;
+            }
+        }
+        if(!__any(active)) {
+            if(__all(exhausted)) break;
+            continue;  // only rays that needed no traversal were drawn: draw again
+        }
+        const bool drained = __any(exhausted);
+
+        for(;;) {
+            if(active && !have) {
+                if(sp > 0) {
+                    --sp;
+                    uint2 e = sp < LDS_STACK ? s_stack[sp * TRACE_BLOCK + tid]
+                                             : sc.spill[(size_t)(sp - LDS_STACK) * nthreads + gtid];
+                    ref = e.x;
+                    tn = __uint_as_float(e.y);
+                    have = true;
+                } else {
+                    sink.store(ray_idx, best);
+                    active = false;
+                }
+            }
+            const int nact = __popcll(__ballot(active));
+            if(nact == 0) break;
+            if(!drained && nact < REFILL_BELOW) break;
+            if(!have) continue;
+
+            const unsigned kind = ref >> 30, idx = ref & REF_INDEX_MASK;
+            if(kind == REF_TRIANGLE) {
+                // intersect_triangle, shader/pathtracing.glsl:224-249 (Moller-Trumbore)
+                const float4 *tp = reinterpret_cast<const float4 *>(sc.tri_pos + idx);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                const float v0x = a.x, v0y = a.y, v0z = a.z;
+                const float e1x = a.w, e1y = b.x, e1z = b.y;
+                const float e2x = b.z, e2y = b.w, e2z = c.x;
+                const float sx = lox - v0x, sy = loy - v0y, sz = loz - v0z;
+                const float s1x = ldy * e2z - e2y * ldz, s1y = ldz * e2x - e2z * ldx, s1z = ldx * e2y - e2x * ldy;
+                const float s2x = sy * e1z - e1y * sz, s2y = sz * e1x - e1z * sx, s2z = sx * e1y - e1x * sy;
+                const float k = 1.0f / (s1x * e1x + s1y * e1y + s1z * e1z);
+                const float t = (s2x * e2x + s2y * e2y + s2z * e2z) * k;
+                const float u = (s1x * sx + s1y * sy + s1z * sz) * k;
+                const float v = (s2x * ldx + s2y * ldy + s2z * ldz) * k;
+                have = false;
+                if(RT_RAY_MINDIS <= t && 0.0f <= u && 0.0f <= v && u + v <= 1.0f && t < best.t) {
+                    best.t = t; best.u = u; best.v = v;
+                    best.tri = (int)idx;
+                    best.inst = cur_inst;
+                    if(any_hit) sp = 0;  // occlusion query: the first accepted hit decides
+                }
+            } else if(tn > best.t) {
+                have = false;  // pruned when taken off the stack
+            } else if(kind == REF_INSTANCE) {
+                // entry into intersect_meshBVH, shader/pathtracing.glsl:254-264
+                const float4 *ip = reinterpret_cast<const float4 *>(sc.inst + idx);
+                const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], bx0 = ip[3], bx1 = ip[4];
+                lox = (r0.x * wox + r0.y * woy) + (r0.z * woz + r0.w);
+                loy = (r1.x * wox + r1.y * woy) + (r1.z * woz + r1.w);
+                loz = (r2.x * wox + r2.y * woy) + (r2.z * woz + r2.w);
+                ldx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
+                ldy = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
+                ldz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
+                cur_inst = (int)idx;
+                ref = __float_as_uint(bx1.z);
+                if((ref >> 30) != REF_TRIANGLE) {
+                    float t0;
+                    have = slab_test(bx0.x, bx0.y, bx0.z, bx0.w, bx1.x, bx1.y, lox, loy, loz, ldx, ldy, ldz, t0);
+                    tn = t0;
+                }
+            } else {
+                const bool mesh = kind == REF_MESH_INNER;
+                const float4 *np = reinterpret_cast<const float4 *>((mesh ? sc.mesh_nodes : sc.scene_nodes) + idx);
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                const float rox = mesh ? lox : wox, roy = mesh ? loy : woy, roz = mesh ? loz : woz;
+                const float rdx = mesh ? ldx : wdx, rdy = mesh ? ldy : wdy, rdz = mesh ? ldz : wdz;
+                float t0, t1;
+                bool p0 = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, rox, roy, roz, rdx, rdy, rdz, t0);
+                bool p1 = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rox, roy, roz, rdx, rdy, rdz, t1);
+                const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                // triangle leaves carry no box test of their own in the reference
+                if((c0 >> 30) == REF_TRIANGLE) { p0 = true; t0 = 0.0f; }
+                if((c1 >> 30) == REF_TRIANGLE) { p1 = true; t1 = 0.0f; }
+                if(p1) {
+                    ref = c1;
+                    tn = t1;
+                    if(p0) {
+                        const uint2 e = make_uint2(c0, __float_as_uint(t0));
+                        if(sp < LDS_STACK) {
+                            s_stack[sp * TRACE_BLOCK + tid] = e;
+                            ++sp;
+                        } else if(sp - LDS_STACK < sc.spill_depth) {
+                            sc.spill[(size_t)(sp - LDS_STACK) * nthreads + gtid] = e;
+                            ++sp;
+                        } else {
+                            *sc.error_flag = 1u;  // host sizes the spill from the tree height; never expected
+                        }
+                    }
+                } else if(p0) {
+                    ref = c0;
+                    tn = t0;
+                } else {
+                    have = false;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace rta

@@ -1,0 +1,145 @@
+#include "accel_layout.h"
+#include <algorithm>
+#include <cstring>
+
+namespace rta {
+namespace {
+
+void set_box(float lo[3], float hi[3], const BVHNodeInfo &n) {
+    for(int k = 0; k < 3; k++) {
+        lo[k] = n.aa[k];
+        hi[k] = n.bb[k];
+    }
+}
+
+// Children are numbered after their parent by both flatteners (breadth-first order), so
+// "child index > own index" proves the arrays form a forest and every walk terminates.
+bool check_children(const BVHNodeInfo *nodes, size_t n, size_t i, const char *what, std::string &err) {
+    const BVHNodeInfo &p = nodes[i];
+    if(p.lsIndex < 0 || p.rsIndex < 0 || (size_t)p.lsIndex >= n || (size_t)p.rsIndex >= n ||
+       (size_t)p.lsIndex <= i || (size_t)p.rsIndex <= i) {
+        err = std::string(what) + " BVH node " + std::to_string(i) + " has invalid child indices";
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo *scene, size_t n_scene_nodes,
+                 const TriangleRec *tris, size_t n_tris, const InstanceInfo *inst, size_t n_inst, AccelHost &out,
+                 std::string &err) {
+    if(n_mesh_nodes == 0 || n_scene_nodes == 0 || n_tris == 0 || n_inst == 0) {
+        err = "scene buffers must not be empty (mesh BVH, scene BVH, triangles, instances)";
+        return false;
+    }
+    if(n_mesh_nodes >= REF_INDEX_MASK || n_tris >= REF_INDEX_MASK || n_inst >= REF_INDEX_MASK) {
+        err = "scene too large for 30-bit references";
+        return false;
+    }
+    // ---- mesh level
+    std::vector<uint32_t> inner_of(n_mesh_nodes, 0);
+    uint32_t n_inner = 0;
+    for(size_t i = 0; i < n_mesh_nodes; i++) {
+        if(mesh[i].triangleIndex >= 0) {
+            if((size_t)mesh[i].triangleIndex >= n_tris) {
+                err = "mesh BVH node " + std::to_string(i) + " references a triangle out of range";
+                return false;
+            }
+        } else {
+            if(!check_children(mesh, n_mesh_nodes, i, "mesh", err)) return false;
+            inner_of[i] = n_inner++;
+        }
+    }
+    auto mesh_ref = [&](int32_t c) {
+        return mesh[c].triangleIndex >= 0 ? make_ref(REF_TRIANGLE, (uint32_t)mesh[c].triangleIndex)
+                                          : make_ref(REF_MESH_INNER, inner_of[c]);
+    };
+    out.mesh_nodes.assign(std::max<size_t>(n_inner, 1), TNode());
+    memset(out.mesh_nodes.data(), 0, out.mesh_nodes.size() * sizeof(TNode));
+    std::vector<int> height(n_mesh_nodes, 1);
+    for(size_t ii = n_mesh_nodes; ii-- > 0;) {
+        const BVHNodeInfo &p = mesh[ii];
+        if(p.triangleIndex >= 0) continue;
+        TNode &t = out.mesh_nodes[inner_of[ii]];
+        set_box(t.lo0, t.hi0, mesh[p.lsIndex]);
+        set_box(t.lo1, t.hi1, mesh[p.rsIndex]);
+        t.c0 = mesh_ref(p.lsIndex);
+        t.c1 = mesh_ref(p.rsIndex);
+        height[ii] = std::max(height[p.lsIndex], height[p.rsIndex]) + 1;
+    }
+    // ---- triangles
+    out.tri_pos.resize(n_tris);
+    for(size_t i = 0; i < n_tris; i++) {
+        const float *v = tris[i].ver;
+        TriPos &t = out.tri_pos[i];
+        for(int k = 0; k < 3; k++) {
+            t.v0[k] = v[k];
+            t.e1[k] = v[3 + k] - v[k];
+            t.e2[k] = v[6 + k] - v[k];
+            t.pad[k] = 0.0f;
+        }
+    }
+    // ---- instances
+    out.instances.resize(n_inst);
+    int max_mesh_height = 1;
+    for(size_t i = 0; i < n_inst; i++) {
+        const InstanceInfo &s = inst[i];
+        if(s.meshIndex < 0 || (size_t)s.meshIndex >= n_mesh_nodes) {
+            err = "instance " + std::to_string(i) + " has a mesh root index out of range";
+            return false;
+        }
+        if(s.materialPtr < 0) {
+            err = "instance " + std::to_string(i) + " has a negative material pointer";
+            return false;
+        }
+        InstAccel &a = out.instances[i];
+        for(int r = 0; r < 3; r++)
+            for(int c = 0; c < 4; c++) a.row[r][c] = s.world2local[c * 4 + r];
+        const BVHNodeInfo &root = mesh[s.meshIndex];
+        set_box(a.root_lo, a.root_hi, root);
+        a.root_ref = mesh_ref(s.meshIndex);
+        a.material_ptr = s.materialPtr;
+        memset(a.pad, 0, sizeof a.pad);
+        max_mesh_height = std::max(max_mesh_height, height[s.meshIndex]);
+    }
+    // ---- scene level
+    std::vector<uint32_t> sinner_of(n_scene_nodes, 0);
+    uint32_t n_sinner = 0;
+    for(size_t i = 0; i < n_scene_nodes; i++) {
+        if(scene[i].instanceIndex >= 0) {
+            if((size_t)scene[i].instanceIndex >= n_inst) {
+                err = "scene BVH node " + std::to_string(i) + " references an instance out of range";
+                return false;
+            }
+        } else {
+            if(!check_children(scene, n_scene_nodes, i, "scene", err)) return false;
+            sinner_of[i] = n_sinner++;
+        }
+    }
+    auto scene_ref = [&](int32_t c) {
+        return scene[c].instanceIndex >= 0 ? make_ref(REF_INSTANCE, (uint32_t)scene[c].instanceIndex)
+                                           : make_ref(REF_SCENE_INNER, sinner_of[c]);
+    };
+    out.scene_nodes.assign(std::max<size_t>(n_sinner, 1), TNode());
+    memset(out.scene_nodes.data(), 0, out.scene_nodes.size() * sizeof(TNode));
+    std::vector<int> sheight(n_scene_nodes, 1);
+    for(size_t ii = n_scene_nodes; ii-- > 0;) {
+        const BVHNodeInfo &p = scene[ii];
+        if(p.instanceIndex >= 0) continue;
+        TNode &t = out.scene_nodes[sinner_of[ii]];
+        set_box(t.lo0, t.hi0, scene[p.lsIndex]);
+        set_box(t.lo1, t.hi1, scene[p.rsIndex]);
+        t.c0 = scene_ref(p.lsIndex);
+        t.c1 = scene_ref(p.rsIndex);
+        sheight[ii] = std::max(sheight[p.lsIndex], sheight[p.rsIndex]) + 1;
+    }
+    set_box(out.header.root_lo, out.header.root_hi, scene[0]);
+    out.header.root_ref = scene_ref(0);
+    out.header.n_instances = (uint32_t)n_inst;
+    // each level of a walk defers at most one sibling
+    out.max_stack = sheight[0] + max_mesh_height;
+    return true;
+}
+
+}  // namespace rta

@@ -1,0 +1,221 @@
+"""Thin Python objects over the C ABI (include/raytracing_amd.h), shaped like the
+reference's classes so that tests read like code written against them:
+
+  Buffer            SSBOBuffer<T>            src/SSBOBuffer.h
+  Texture           Texture / sky textures   src/texture/Texture.cpp, Skybox.cpp
+  PathTracingPass   Renderer                 src/renderpass/Renderer.{h,cpp}
+  SceneBuffers      the seven SSBO members of ResourceManager (src/ResourceManager.h:84-90)
+
+Every call goes through libraytracing_amd.so; there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import PtStats, check, lib
+
+HIT_DTYPE = np.dtype([("instance", "<i4"), ("triangle", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+
+SLOT_TEXTURE_HANDLES, SLOT_MATERIAL, SLOT_TRIANGLE, SLOT_INSTANCE_INFO, SLOT_MESH_BVH, SLOT_SCENE_BVH, SLOT_LIGHT = range(7)
+OUT_ALBEDO, OUT_MOTION, OUT_DEPTH, OUT_NORMAL, OUT_INSTANCE_INDEX, OUT_DIRECT_LUM, OUT_INDIRECT_LUM = 7, 9, 11, 12, 13, 14, 15
+OUTPUTS = {"albedo": (OUT_ALBEDO, 3), "motion": (OUT_MOTION, 2), "depth": (OUT_DEPTH, 1), "normal": (OUT_NORMAL, 3),
+           "instanceIndex": (OUT_INSTANCE_INDEX, 1), "directLum": (OUT_DIRECT_LUM, 3),
+           "indirectLum": (OUT_INDIRECT_LUM, 3)}
+
+
+class Context:
+    def __init__(self, device_id=0):
+        h = C.c_void_p()
+        check(lib.pt_ctx_create(device_id, C.byref(h)))
+        self.h = h
+
+    def synchronize(self):
+        check(lib.pt_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib.pt_ctx_stream(self.h)
+
+    def destroy(self):
+        if self.h:
+            lib.pt_ctx_destroy(self.h)
+            self.h = None
+
+
+class Buffer:
+    """SSBOBuffer: construct from a size or from host data; release() explicitly."""
+
+    def __init__(self, ctx, data=None, nbytes=None, _borrowed=None):
+        self.ctx = ctx
+        if _borrowed is not None:
+            self.h = _borrowed
+            self.owned = False
+            return
+        self.owned = True
+        h = C.c_void_p()
+        if data is not None:
+            a = np.ascontiguousarray(data)
+            check(lib.pt_buf_create(ctx.h, a.nbytes, a.ctypes.data if a.nbytes else None, C.byref(h)))
+        else:
+            check(lib.pt_buf_create(ctx.h, int(nbytes), None, C.byref(h)))
+        self.h = h
+
+    @property
+    def nbytes(self):
+        return lib.pt_buf_bytes(self.h)
+
+    @property
+    def device_ptr(self):
+        return lib.pt_buf_device_ptr(self.h)
+
+    def isempty(self):
+        return self.h is None
+
+    def copy_from_host(self, data):
+        a = np.ascontiguousarray(data)
+        check(lib.pt_buf_upload(self.h, a.ctypes.data, a.nbytes))
+
+    def copy_from(self, other):
+        check(lib.pt_buf_copy(self.h, other.h))
+
+    def fill(self, value, dtype=np.float32):
+        v = np.array([value], dtype)
+        check(lib.pt_buf_fill(self.h, v.ctypes.data, v.nbytes))
+
+    def download(self, dtype=np.float32, count=None):
+        n = self.nbytes if count is None else count * np.dtype(dtype).itemsize
+        out = np.zeros(n // np.dtype(dtype).itemsize, dtype)
+        check(lib.pt_buf_download(self.h, out.ctypes.data, out.nbytes))
+        return out
+
+    def release(self):
+        if self.h and self.owned:
+            lib.pt_buf_release(self.h)
+        self.h = None
+
+
+class Texture:
+    def __init__(self, ctx, pixels):
+        a = np.ascontiguousarray(pixels)
+        assert a.ndim == 3 and a.dtype in (np.uint8, np.float32)
+        h = C.c_void_p()
+        check(lib.pt_tex_create(ctx.h, a.shape[1], a.shape[0], a.shape[2], 0 if a.dtype == np.uint8 else 1,
+                                a.ctypes.data, C.byref(h)))
+        self.h = h
+
+    @property
+    def handle(self):
+        return lib.pt_tex_handle(self.h)
+
+    def release(self):
+        if self.h:
+            lib.pt_tex_release(self.h)
+            self.h = None
+
+
+class SceneBuffers:
+    """Uploads a scene.SceneData (+ optional scene.Sky) the way ResourceManager does."""
+
+    def __init__(self, ctx, scene_data, sky=None):
+        sd = scene_data
+        self.ctx = ctx
+        self.textures = [Texture(ctx, t) for t in sd.textures]
+        handles = np.array([t.handle for t in self.textures], np.uint64)
+        self.textureHandleSSBO = Buffer(ctx, handles)
+        self.materialSSBO = Buffer(ctx, sd.materials)
+        self.triangleSSBO = Buffer(ctx, sd.triangles)
+        self.instanceInfoSSBO = Buffer(ctx, sd.instances)
+        self.meshBVHSSBO = Buffer(ctx, sd.mesh_nodes)
+        self.sceneBVHSSBO = Buffer(ctx, sd.scene_nodes)
+        self.lightSSBO = Buffer(ctx, sd.lights)
+        self.light_count = len(sd.lights)
+        self.sky = sky
+        self.sky_tex = Texture(ctx, sky.rgb) if sky is not None else None
+        self.sky_cache_tex = Texture(ctx, sky.cache) if sky is not None else None
+
+    def buffers(self):
+        return [self.textureHandleSSBO, self.materialSSBO, self.triangleSSBO, self.instanceInfoSSBO,
+                self.meshBVHSSBO, self.sceneBVHSSBO, self.lightSSBO]
+
+    def release(self):
+        for b in self.buffers():
+            b.release()
+        for t in self.textures + [self.sky_tex, self.sky_cache_tex]:
+            if t is not None:
+                t.release()
+
+
+class PathTracingPass:
+    """Renderer: seven public output buffers, draw() = one sample per pixel."""
+
+    def __init__(self, ctx, width, height):
+        self.ctx = ctx
+        self.width, self.height = width, height
+        h = C.c_void_p()
+        check(lib.pt_pass_create(ctx.h, width, height, C.byref(h)))
+        self.h = h
+        self.outputs = {}
+        for name, (slot, _) in OUTPUTS.items():
+            b = C.c_void_p()
+            check(lib.pt_pass_output(self.h, slot, C.byref(b)))
+            self.outputs[name] = Buffer(ctx, _borrowed=b)
+        # the reference's member names (Renderer.h:19-25)
+        self.directLumGBufferSSBO = self.outputs["directLum"]
+        self.indirectLumGBufferSSBO = self.outputs["indirectLum"]
+        self.motionGBufferSSBO = self.outputs["motion"]
+        self.albedoGBufferSSBO = self.outputs["albedo"]
+        self.depthGBufferSSBO = self.outputs["depth"]
+        self.normalGBufferSSBO = self.outputs["normal"]
+        self.instanceIndexGBufferSSBO = self.outputs["instanceIndex"]
+
+    def bind_scene(self, sb):
+        for slot, buf in enumerate(sb.buffers()):
+            check(lib.pt_pass_bind(self.h, slot, buf.h))
+        if sb.sky_tex is not None:
+            self.bind_texture("skybox", sb.sky_tex)
+            self.bind_texture("skybox_samplecache", sb.sky_cache_tex)
+
+    def bind(self, slot, buf):
+        check(lib.pt_pass_bind(self.h, slot, buf.h if buf is not None else None))
+
+    def bind_texture(self, name, tex):
+        check(lib.pt_pass_bind_texture(self.h, name.encode(), tex.h if tex is not None else None))
+
+    def set_params(self, params):
+        check(lib.pt_pass_set_params(self.h, C.byref(params)))
+
+    def draw(self):
+        check(lib.pt_pass_draw(self.h))
+
+    def intersect(self, rays_buf, n, hits_buf):
+        check(lib.pt_pass_intersect(self.h, rays_buf.h, n, hits_buf.h))
+
+    def stats(self, reset=False):
+        s = PtStats()
+        check(lib.pt_pass_stats(self.h, C.byref(s), int(reset)))
+        return dict(samples=int(s.samples), rays_extend=int(s.rays_extend), rays_shadow=int(s.rays_shadow),
+                    draws=int(s.draws))
+
+    def download(self):
+        out = {}
+        for name, (_, c) in OUTPUTS.items():
+            out[name] = self.outputs[name].download(np.float32).reshape(self.height, self.width, c)
+        return out
+
+    def destroy(self):
+        if self.h:
+            lib.pt_pass_destroy(self.h)
+            self.h = None
+
+
+def trace_rays(pass_, rays):
+    """Convenience: closest hits (HIT_DTYPE array) for host rays (n, 6)."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    rb = Buffer(pass_.ctx, rays)
+    hb = Buffer(pass_.ctx, nbytes=len(rays) * HIT_DTYPE.itemsize)
+    pass_.intersect(rb, len(rays), hb)
+    hits = hb.download(np.uint8).view(HIT_DTYPE)
+    rb.release()
+    hb.release()
+    return hits
