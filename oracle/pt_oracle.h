@@ -18,6 +18,9 @@
  *   - no fused multiply-add anywhere (build with -ffp-contract=off);
  *   - a / b is IEEE division, sqrt is IEEE, normalize(v) = v * (1 / sqrt(dot(v, v)));
  *   - min / max drop a NaN operand (fminf / fmaxf);
+ *   - sin, cos, atan, asin and pow (GLSL bounds their error, not their value) follow one
+ *     fixed fp32 recipe (pt_oracle.cpp, "sin / cos / atan / asin / pow"), abs. error ~1e-7;
+ *     tan(fov/2) is the C library's;
  *   - mat4 * vec4 associates as (m0*x + m1*y) + (m2*z + m3*w) like glm;
  *   - texture(): GL 4.6 section 8.14 bilinear filter evaluated in fp32, REPEAT wrap;
  *   - the varying screen_uv is ((x + 0.5) / W, (y + 0.5) / H);

@@ -1,5 +1,6 @@
 // Device half of the C ABI: context, buffers, textures and the path-tracing pass.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -535,6 +536,7 @@ int pt_pass_draw(pt_pass *p) {
     DrawParams dp;
     memset(&dp, 0, sizeof dp);
     dp.p = P;
+    dp.tan_half_fov = std::tan(P.fov / 2.0f);
     dp.W = p->W; dp.H = p->H; dp.npix = (int)npix;
     dp.n_shadow = n_shadow;
     dp.materials = static_cast<const float *>(p->slots[PT_SLOT_MATERIAL]->dptr);

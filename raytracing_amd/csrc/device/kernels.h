@@ -11,6 +11,7 @@ namespace rta {
 // Everything one draw needs, passed to the kernels by value.
 struct DrawParams {
     pt_params p;
+    float tan_half_fov;  // tan(fov / 2), evaluated once on the host
     int W, H, npix;
     int n_shadow;  // shadow entries per pixel = 1 (sky) + lightCount
     // scene

@@ -33,10 +33,11 @@ __device__ __forceinline__ unsigned pixel_seed(const pt_params &p, unsigned px, 
 }
 
 // camera ray, :604-608
-__device__ __forceinline__ void camera_ray(const pt_params &p, unsigned px, unsigned py, V3 &ori, V3 &dir) {
+__device__ __forceinline__ void camera_ray(const pt_params &p, float tan_half_fov, unsigned px, unsigned py, V3 &ori,
+                                           V3 &dir) {
     const int W = p.SCREEN_W, H = p.SCREEN_H;
     float p_x = (float)px + p.jitter[0], p_y = (float)py + p.jitter[1];
-    float disz = (float)W * 0.5f / tanf(p.fov / 2.0f);
+    float disz = (float)W * 0.5f / tan_half_fov;
     const float *m = p.v2wMat;
     ori = v3(m[12], m[13], m[14]);
     float cx = p_x - (float)(W / 2), cy = p_y - (float)(H / 2), cz = -disz;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
     for(unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)dp.npix; i += nthreads) {
         const unsigned px = i % (unsigned)dp.W, py = i / (unsigned)dp.W;
         V3 o, d;
-        camera_ray(dp.p, px, py, o, d);
+        camera_ray(dp.p, dp.tan_half_fov, px, py, o, d);
         float4 *r = reinterpret_cast<float4 *>(dp.rays + i);
         r[0] = make_float4(o.x, o.y, o.z, 0.0f);
         r[1] = make_float4(d.x, d.y, d.z, 0.0f);

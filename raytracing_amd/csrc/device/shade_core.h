@@ -4,10 +4,11 @@
 //
 // Expressions are written with the operand order and association of the GLSL source and
 // must stay unfused (-ffp-contract=off); the CPU checker evaluates the same expressions,
-// so the two differ only where sin/cos/tan/atan/asin/pow of the two math libraries do.
+// and sin/cos/atan/asin/pow come from the fixed recipes of shade_math.h, so the two agree bit for bit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_types.h"
+#include "shade_math.h"
 
 namespace rta {
 
@@ -48,7 +49,7 @@ __device__ __forceinline__ int roundint(float x) {
 }
 __device__ __forceinline__ float pow2(float x) { return x * x; }
 __device__ __forceinline__ float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
-__device__ __forceinline__ V3 powv(V3 v, float n) { return v3(powf(v.x, n), powf(v.y, n), powf(v.z, n)); }
+__device__ __forceinline__ V3 powv(V3 v, float n) { return v3(rt_pow(v.x, n), rt_pow(v.y, n), rt_pow(v.z, n)); }
 __device__ __forceinline__ V3 refract_custom(V3 I, V3 N, float eta) {
     float c1 = dot(N, -I);
     float s1 = sqrtf(1.0f - c1 * c1);
@@ -164,7 +165,7 @@ struct ShadeCtx {
         float phi = rng.rand() * 2.0f * S_PI;
         float r = sqrtf(1.0f - cos2);
         pdf = 2.0f * alpha2 * cos_theta / pow2(cos2 * (alpha2 - 1.0f) + 1.0f) / (2.0f * S_PI);
-        return normalize(v3(r * cosf(phi), r * sinf(phi), cos_theta));
+        return normalize(v3(r * rt_cos(phi), r * rt_sin(phi), cos_theta));
     }
     __device__ static float eval_GGX(float alpha, V3 h) {
         float cos_theta = fabsf(h.z);
@@ -340,10 +341,10 @@ struct ShadeCtx {
         float r = fmaxf(0.0f, sqrtf(1.0f - z * z));
         float phi = 2.0f * S_PI * rng.rand();
         pdf = 0.25f * S_INV_PI;
-        return v3(r * cosf(phi), r * sinf(phi), z);
+        return v3(r * rt_cos(phi), r * rt_sin(phi), z);
     }
     __device__ V3 get_background_color(V3 v) const {
-        float ux = atan2f(v.z, v.x), uy = asinf(v.y);
+        float ux = rt_atan2(v.z, v.x), uy = rt_asin(v.y);
         ux /= 2.0f * S_PI;
         uy /= S_PI;
         ux += 0.5f;
@@ -362,8 +363,8 @@ struct ShadeCtx {
         V3 samp = texture_rgb(sky_cache, x, y);
         float theta = (samp.x - 0.5f) * 2.0f * S_PI;
         float phi = (1.0f - samp.y - 0.5f) * S_PI;
-        float r = cosf(phi);
-        V3 wi = v3(r * cosf(theta), sinf(phi), r * sinf(theta));
+        float r = rt_cos(phi);
+        V3 wi = v3(r * rt_cos(theta), rt_sin(phi), r * rt_sin(theta));
         pdf = samp.z / w2a_of(wi.y);
         return wi;
     }
