@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Throughput of the path-tracing pass on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload casa_pt|casa_isect|synth_pt]
+
+One step = one pass of the hot path over one batch:
+  casa_pt    one pt_pass_draw (1 sample per pixel) of the casa demo scene at 1920x1080,
+             MAX_DEPTH 8, sky NEE + BSDF sampling (the "casa 1080p" configuration the
+             headline metric is quoted on; 64 steps = the 64-spp frame)            [default]
+  casa_isect one pt_pass_intersect over 16 Mi random incoherent rays vs the casa BVH
+  synth_pt   one draw of a procedural 10 M-triangle scene at 3840x2160, MAX_DEPTH 8
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds the
+whole scene and renders its own slice of the samples (global sample s belongs to rank
+(s-1) % N); accumulators are kept as sums and combined with ONE all-reduce (RCCL) at the
+end of the timed region.  Scaling is weak: every rank does K steps.
+
+Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="casa_pt", choices=["casa_pt", "casa_isect", "synth_pt"])
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--tris", type=int, default=10_000_000, help="synth_pt: triangle count")
+    ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel events (no roofline)")
+    return ap.parse_args()
+
+
+def dev_tensor(torch, ptr, n_floats):
+    """float32 torch view of device memory owned by the library (no copy)."""
+    class _Arr:
+        pass
+    a = _Arr()
+    a.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(a, device="cuda")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the pass has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from raytracing_amd import device, multigpu, scene
+
+    wl = args.workload
+    steps = args.steps if args.steps is not None else (64 if wl == "casa_pt" else (8 if wl == "casa_isect" else 16))
+    warmup = args.warmup if args.warmup is not None else (4 if wl != "casa_isect" else 2)
+
+    t_setup = time.time()
+    if wl == "synth_pt":
+        sd = scene.synthetic_scene(args.tris)
+        W, H = args.width or 3840, args.height or 2160
+        v2w = scene.synthetic_camera()
+    else:
+        sd = scene.casa_scene(os.path.join(ROOT, "assets", "casa_obj.glb"))
+        W, H = args.width or 1920, args.height or 1080
+        v2w = scene.casa_camera()
+    sky = scene.procedural_sky(2048, 1024)
+    ctx = device.Context(local_rank)
+    sb = device.SceneBuffers(ctx, sd, sky)
+    npix = W * H
+    p = device.PathTracingPass(ctx, W if wl != "casa_isect" else 16, H if wl != "casa_isect" else 16)
+    p.bind_scene(sb)
+    setup_s = time.time() - t_setup
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    result = {}
+    if wl == "casa_isect":
+        lo, hi = sd.world_box()
+        rays = scene.random_rays(lo, hi, args.rays, 7 + rank)
+        rb = device.Buffer(ctx, rays)
+        hb = device.Buffer(ctx, nbytes=args.rays * device.HIT_DTYPE.itemsize)
+        for _ in range(warmup):
+            p.intersect(rb, args.rays, hb)
+        barrier()
+        if not args.no_profile:
+            p.set_profiling(True)
+            p.profile(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.intersect(rb, args.rays, hb)
+        barrier()
+        dt = time.perf_counter() - t0
+        total_rays = args.rays * steps
+        units_per_rank = dict(rays=total_rays, samples=0, rays_extend=total_rays, rays_shadow=0)
+        prof = p.profile() if not args.no_profile else None
+        dominant = ("intersect_kernel", prof["intersect_ms"], prof["intersect_launches"], total_rays) if prof else None
+    else:
+        total_spp = steps * world
+        jit = scene.mt19937_jitters(total_spp)
+        my_samples = multigpu.sample_slice(total_spp, rank, world)  # 1-based global sample indices
+
+        def draw(global_s, accum_mode):
+            # currentspp carries the GLOBAL sample index (it seeds the sampler); with sums
+            # (accum_mode 1) the accumulation weight does not depend on it
+            prm = scene.make_params(W, H, v2w, sky, spp=global_s, frame=1, jitter=jit[(global_s - 1) % total_spp],
+                                    max_depth=args.depth, light_count=len(sd.lights), accum_mode=accum_mode)
+            p.set_params(prm)
+            p.draw()
+
+        for k in range(warmup):
+            draw(1 + k, 0)
+        accum_mode = 1 if world > 1 else 0
+        if world > 1:
+            for name in multigpu.ACCUMULATED:   # sums start from zero on every rank
+                p.outputs[name].fill(0.0)
+        barrier()
+        p.stats(reset=True)
+        if not args.no_profile:
+            p.set_profiling(True)
+            p.profile(reset=True)
+        t0 = time.perf_counter()
+        for s in my_samples:
+            draw(s, accum_mode)
+        if world > 1:
+            ctx.synchronize()
+            multigpu.allreduce_outputs(torch, dist, p, npix, total_spp, dev_tensor)
+        barrier()
+        dt = time.perf_counter() - t0
+        st = p.stats()
+        units_per_rank = dict(rays=st["rays_extend"] + st["rays_shadow"], samples=st["samples"],
+                              rays_extend=st["rays_extend"], rays_shadow=st["rays_shadow"])
+        prof = p.profile() if not args.no_profile else None
+        dominant = ("extend_kernel", prof["extend_ms"], prof["extend_launches"], st["rays_extend"]) if prof else None
+
+    # max time over ranks, sum of units over ranks
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        uu = torch.tensor([units_per_rank["rays"], units_per_rank["samples"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+        total_rays, total_samples = float(uu[0].item()), float(uu[1].item())
+    else:
+        total_rays, total_samples = float(units_per_rank["rays"]), float(units_per_rank["samples"])
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s",
+            "value": total_rays / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "casa_obj.glb (reference demo scene) + procedural 2048x1024 sky" if wl != "synth_pt"
+                    else "synthetic procedural scene + procedural 2048x1024 sky",
+            "config": {"workload": {"casa_pt": "casa 1920x1080 path trace, 1 spp per step, max depth %d, sky NEE + BSDF sampling" % args.depth,
+                                    "casa_isect": "intersection only: %d random incoherent rays vs casa BVH per step" % args.rays,
+                                    "synth_pt": "synthetic %d-triangle scene %dx%d path trace, 1 spp per step, max depth %d" % (len(sd.triangles), W, H, args.depth)}[wl],
+                       "resolution": [W, H] if wl != "casa_isect" else None,
+                       "triangles": int(len(sd.triangles)), "instances": int(len(sd.instances)),
+                       "parallelism": "sample slicing x%d, one all-reduce" % world if world > 1 else "single GPU"},
+            "msamples_per_s": total_samples / dt / 1e6,
+            "rays_per_sample": (total_rays / total_samples) if total_samples else None,
+            "setup_s": setup_s,
+        }
+        # ---- CPU baseline + algorithmic bytes per ray (oracle, bounded sample)
+        b_ray = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle
+            osc = oracle.OracleScene(sd, sky)
+            cores = min(16, os.cpu_count() or 1)
+            if wl == "casa_isect":
+                n_s = min(args.rays, 1 << 21)
+                t1 = time.perf_counter()
+                hits, cnt = osc.intersect(rays[:n_s], n_threads=cores)
+                cdt = time.perf_counter() - t1
+                got = hb.download(np.uint8).view(device.HIT_DTYPE)[:n_s]
+                parity = bool(np.array_equal(got["triangle"], hits["triangle"]) and np.array_equal(got["instance"], hits["instance"])
+                              and np.array_equal(got["t"].view(np.uint32), hits["t"].view(np.uint32)))
+                b_ray = oracle.algorithmic_bytes_per_ray(cnt)
+                out["cpu_baseline"] = {"value": n_s / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                       "sample": "first %d of the %d rays of one step" % (n_s, args.rays)}
+                out["parity_vs_oracle"] = "bit-exact ids and t on the sample" if parity else "MISMATCH"
+            else:
+                # the sample: the last spp of the timed frame, rendered again on the CPU
+                sw, sh = (W, H) if wl == "casa_pt" else (W // 4, H // 4)
+                s_last = steps
+                prm = scene.make_params(sw, sh, v2w, sky, spp=1, frame=s_last, jitter=jit[s_last - 1], max_depth=args.depth,
+                                        light_count=len(sd.lights))
+                t1 = time.perf_counter()
+                ref, cnt = osc.render(prm, n_threads=cores)
+                cdt = time.perf_counter() - t1
+                c_rays = cnt["rays_extend"] + cnt["rays_shadow"]
+                b_ray = oracle.algorithmic_bytes_per_extend_ray(cnt)
+                if (sw, sh) == (W, H):
+                    # the same sample once more on the GPU, outside the timed region: live parity
+                    p.set_profiling(False)
+                    p.set_params(prm)
+                    p.draw()
+                    got = p.download()
+                    same = all(bool(np.all((got[k].view(np.uint32) == ref[k].view(np.uint32)) | (got[k] == ref[k])
+                                           | (np.isnan(got[k]) & np.isnan(ref[k])))) for k in ref)
+                    out["parity_vs_oracle"] = ("all 7 outputs bit-equal for sample %d at %dx%d" % (s_last, W, H)) if same else "MISMATCH"
+                out["cpu_baseline"] = {"value": c_rays / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                       "sample": "1 spp of the same frame at %dx%d (%d rays), OpenMP over rows" % (sw, sh, c_rays)}
+                out["algorithmic_bytes"] = {"per_extend_ray": b_ray,
+                                            "per_any_ray": oracle.algorithmic_bytes_per_ray(cnt)}
+        # ---- roofline of the dominant kernel
+        if dominant is not None and dominant[2] > 0:
+            name, ms, launches, rays_in_kernel = dominant
+            if b_ray is None:
+                b_ray = float(os.environ.get("RT_B_RAY", "0")) or None
+            if b_ray is not None:
+                achieved = rays_in_kernel * b_ray / (ms * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "avg_launch_ms": ms / launches, "launches": int(launches),
+                                   "algorithmic_bytes_per_ray": b_ray,
+                                   "rays_per_launch": rays_in_kernel / launches}
+            if prof:
+                out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms")}
+        print(json.dumps(out), flush=True)
+
+    p.destroy()
+    sb.release()
+    ctx.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,6 +157,18 @@ typedef struct pt_stats {
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 
+/* Per-kernel device time, measured with HIP events recorded on the context's stream around
+ * every launch while profiling is enabled.  No counterpart in the reference (its only
+ * timing is an FPS counter, main.cpp:423-435); used by bench.py for the roofline figure. */
+typedef struct pt_profile {
+    double extend_ms, shadow_ms, shade_ms, other_ms; /* other = generate, shadow-apply, finalize */
+    double intersect_ms;                             /* pt_pass_intersect launches            */
+    uint64_t extend_launches, shadow_launches, shade_launches, other_launches, intersect_launches;
+} pt_profile;
+int pt_pass_set_profiling(pt_pass *pass, int enable);
+/* Waits for the stream, then reports the time accumulated since the last reset. */
+int pt_pass_profile(pt_pass *pass, pt_profile *out, int reset);
+
 /* Closest hit for n rays against the scene bound to the pass: intersect_sceneBVH,
  * shader/pathtracing.glsl:292-316, exposed on its own.  rays: n * 6 floats
  * (origin xyz, direction xyz; the direction is used as given).  hits: n records. */

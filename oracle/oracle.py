@@ -44,7 +44,8 @@ class OrcOutputs(C.Structure):
 
 
 COUNTER_FIELDS = ("rays", "scene_nodes", "mesh_inner_nodes", "leaf_tests", "hits", "max_stack", "samples",
-                  "rays_extend", "rays_shadow", "shaded_vertices", "material_evals", "ldr_tex_fetches", "sky_fetches")
+                  "rays_extend", "rays_shadow", "shaded_vertices", "material_evals", "ldr_tex_fetches", "sky_fetches",
+                  "ext_nodes", "ext_leaf_tests")
 
 
 class OrcCounters(C.Structure):
@@ -142,6 +143,12 @@ def algorithmic_bytes_per_ray(cnt):
     rays = max(1, cnt["rays"])
     nodes = cnt["scene_nodes"] + cnt["mesh_inner_nodes"] + cnt["leaf_tests"]
     return (48.0 * nodes + 36.0 * cnt["leaf_tests"]) / rays + 24.0 + 12.0
+
+
+def algorithmic_bytes_per_extend_ray(cnt):
+    """Same figure restricted to the closest-hit rays of a render (primary + indirect)."""
+    rays = max(1, cnt["rays_extend"])
+    return (48.0 * cnt["ext_nodes"] + 36.0 * cnt["ext_leaf_tests"]) / rays + 24.0 + 12.0
 
 
 # ------------------------------------------------------------------ compiled reference

@@ -219,6 +219,7 @@ struct Ctx {
     uint32_t sobolseed = 0, sobolcurdim = 0;
     int stack_h = 0;
     int stack[256];
+    bool counting_extend = true;  // false while a shadow ray is traced
     orc_counters cnt;
     Ctx() { memset(&cnt, 0, sizeof cnt); }
 
@@ -554,8 +555,10 @@ struct Ctx {
         while(stack_h > starth) {
             int id = stack[stack_h--];
             const Node &cur = nodes[id];
+            if(counting_extend) cnt.ext_nodes++;
             if(cur.tri >= 0) {
                 cnt.leaf_tests++;
+                if(counting_extend) cnt.ext_leaf_tests++;
                 Intersection isect = intersect_triangle(ray, cur.tri);
                 if(isect.exist && isect.t < result.t) {
                     // normal * mat3(w2l): row vector times matrix = dot with each column
@@ -590,6 +593,7 @@ struct Ctx {
             int id = stack[stack_h--];
             const Node &cur = nodes[id];
             cnt.scene_nodes++;
+            if(counting_extend) cnt.ext_nodes++;
             float tnear;
             if(!intersect_aabb(ray, cur.aa, cur.bb, tnear)) continue;
             if(tnear > result.t) continue;
@@ -670,7 +674,9 @@ struct Ctx {
                 global_wo = skybox_sample(pdf);
                 if(pdf > 0.0f) {
                     cnt.rays_shadow++;
+                    counting_extend = false;
                     Intersection tsect = intersect_sceneBVH(Ray{isect.position, global_wo});
+                    counting_extend = true;
                     if(!tsect.exist) {
                         bRec.wo = to_local(coord, global_wo);
                         vec3 fr = eval_material(bRec);
@@ -696,7 +702,9 @@ struct Ctx {
                     radiance = vec3(light.r, light.g, light.b);
                 }
                 cnt.rays_shadow++;
+                counting_extend = false;
                 Intersection tsect = intersect_sceneBVH(Ray{isect.position, dir});
+                counting_extend = true;
                 if(!tsect.exist || tsect.t * tsect.t > dis2) {
                     bRec.wo = to_local(coord, dir);
                     vec3 fr = eval_material(bRec);

@@ -99,6 +99,8 @@ typedef struct orc_counters {
     uint64_t material_evals;   /* eval/pdf/sample/albedo dispatches                 */
     uint64_t ldr_tex_fetches;  /* bilinear fetches of 8-bit textures                */
     uint64_t sky_fetches;      /* bilinear fetches of sky or sample cache           */
+    uint64_t ext_nodes;        /* nodes popped (scene + mesh inner + leaf) by extend rays only */
+    uint64_t ext_leaf_tests;   /* triangle tests by extend rays only                */
 } orc_counters;
 
 /* intersect_sceneBVH (pathtracing.glsl:292-316) for n rays (6 floats each). */

@@ -50,6 +50,13 @@ class PtStats(C.Structure):
     ]
 
 
+class PtProfile(C.Structure):
+    _fields_ = [("extend_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
+                ("other_ms", C.c_double), ("intersect_ms", C.c_double),
+                ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64), ("shade_launches", C.c_uint64),
+                ("other_launches", C.c_uint64), ("intersect_launches", C.c_uint64)]
+
+
 # name -> (restype, argtypes); also the list the symbol-export test walks
 SIGNATURES = {
     "pt_last_error": (C.c_char_p, []),
@@ -77,6 +84,8 @@ SIGNATURES = {
     "pt_pass_draw": (C.c_int, [C.c_void_p]),
     "pt_pass_output": (C.c_int, [C.c_void_p, C.c_int, c_void_pp]),
     "pt_pass_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats), C.c_int]),
+    "pt_pass_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_pass_profile": (C.c_int, [C.c_void_p, C.POINTER(PtProfile), C.c_int]),
     "pt_pass_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pt_host_build_mesh_bvh": (C.c_int, [C.c_void_p, i32p, C.c_int32, C.c_int32, C.c_void_p, f32p, i32p, i32p]),
     "pt_host_build_scene": (C.c_int, [f32p, i32p, i32p, C.c_int32, f32p, i32p, i32p, C.c_int32,

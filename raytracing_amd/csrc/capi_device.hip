@@ -98,6 +98,12 @@ struct pt_pass {
     DeviceArray d_rays, d_hits, d_thr, d_acc, d_shadow, d_queue_a, d_queue_b, d_queue_s, d_counters, d_stats, d_err;
     int shadow_capacity = 0;
     int trace_blocks = 0;
+    // optional per-kernel timing
+    bool profiling = false;
+    struct Timed { int kind; hipEvent_t a, b; };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> event_pool;
+    pt_profile prof;
 };
 
 namespace {
@@ -235,6 +241,55 @@ TraceScene make_trace_scene(pt_pass *p) {
     sc.spill_depth = p->spill_depth;
     sc.error_flag = static_cast<unsigned *>(p->d_err.p);
     return sc;
+}
+
+enum { K_EXTEND = 0, K_SHADOW = 1, K_SHADE = 2, K_OTHER = 3, K_INTERSECT = 4 };
+
+// Brackets one launch with two events when profiling is on.
+struct ScopedTimer {
+    pt_pass *p;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind;
+    static hipEvent_t take(pt_pass *p) {
+        if(!p->event_pool.empty()) {
+            hipEvent_t e = p->event_pool.back();
+            p->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    ScopedTimer(pt_pass *pass, int k) : p(pass), kind(k) {
+        if(!p->profiling) return;
+        a = take(p);
+        b = take(p);
+        if(a) (void)hipEventRecord(a, p->ctx->stream);
+    }
+    ~ScopedTimer() {
+        if(!p->profiling || !a || !b) return;
+        (void)hipEventRecord(b, p->ctx->stream);
+        p->timed.push_back({kind, a, b});
+    }
+};
+
+// Folds finished event pairs into the profile (the stream must be idle).
+void collect_profile(pt_pass *p) {
+    for(auto &t : p->timed) {
+        float ms = 0.0f;
+        if(hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            switch(t.kind) {
+                case K_EXTEND: p->prof.extend_ms += ms; p->prof.extend_launches++; break;
+                case K_SHADOW: p->prof.shadow_ms += ms; p->prof.shadow_launches++; break;
+                case K_SHADE: p->prof.shade_ms += ms; p->prof.shade_launches++; break;
+                case K_INTERSECT: p->prof.intersect_ms += ms; p->prof.intersect_launches++; break;
+                default: p->prof.other_ms += ms; p->prof.other_launches++; break;
+            }
+        }
+        p->event_pool.push_back(t.a);
+        p->event_pool.push_back(t.b);
+    }
+    p->timed.clear();
 }
 
 TexDesc desc_of(const pt_tex *t) {
@@ -433,6 +488,7 @@ int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
     p->W = screen_w;
     p->H = screen_h;
     memset(&p->params, 0, sizeof p->params);
+    memset(&p->prof, 0, sizeof p->prof);
     const size_t npix = (size_t)screen_w * screen_h;
     int rc = PT_OK;
     for(int k = 0; k < 7 && !rc; k++) rc = pt_buf_create(ctx, npix * OUT_CHANNELS[k] * sizeof(float), nullptr, &p->outputs[k]);
@@ -467,6 +523,8 @@ int pt_pass_destroy(pt_pass *p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     for(int k = 0; k < 7; k++) pt_buf_release(p->outputs[k]);
+    collect_profile(p);
+    for(hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
     DeviceArray *arrs[] = {&p->d_mesh_nodes, &p->d_scene_nodes, &p->d_tri_pos, &p->d_inst, &p->d_spill, &p->d_tex_table,
                            &p->d_rays, &p->d_hits, &p->d_thr, &p->d_acc, &p->d_shadow, &p->d_queue_a, &p->d_queue_b,
                            &p->d_queue_s, &p->d_counters, &p->d_stats, &p->d_err};
@@ -568,22 +626,38 @@ int pt_pass_draw(pt_pass *p) {
     hipStream_t s = ctx->stream;
     const TraceScene sc = make_trace_scene(p);
     HIP_TRY(hipMemsetAsync(cnt, 0, CNT_TOTAL * 4, s));
-    launch_generate(s, dp);
+    {
+        ScopedTimer t(p, K_OTHER);
+        launch_generate(s, dp);
+    }
     unsigned *qa = static_cast<unsigned *>(p->d_queue_a.p), *qb = static_cast<unsigned *>(p->d_queue_b.p);
     unsigned *qs = static_cast<unsigned *>(p->d_queue_s.p);
     const unsigned *q_in = nullptr;  // vertex 0: every pixel, in pixel order
     for(int dep = 0; dep <= P.MAX_DEPTH; dep++) {
         unsigned *q_out = (dep & 1) ? qb : qa;
-        launch_extend(s, sc, p->trace_blocks, q_in, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
-        launch_shade(s, dp, dep, q_in, cnt + CNT_QUEUE + dep, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep);
+        {
+            ScopedTimer t(p, K_EXTEND);
+            launch_extend(s, sc, p->trace_blocks, q_in, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
+        }
+        {
+            ScopedTimer t(p, K_SHADE);
+            launch_shade(s, dp, dep, q_in, cnt + CNT_QUEUE + dep, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep);
+        }
         if(dep < P.MAX_DEPTH) {
-            launch_shadow(s, sc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
-                          cnt + CNT_NEXT + 2 * dep + 1);
+            {
+                ScopedTimer t(p, K_SHADOW);
+                launch_shadow(s, sc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
+                              cnt + CNT_NEXT + 2 * dep + 1);
+            }
+            ScopedTimer t(p, K_OTHER);
             launch_shadow_apply(s, dp, qs, cnt + CNT_SHADOW + dep);
         }
         q_in = q_out;
     }
-    launch_finalize(s, dp);
+    {
+        ScopedTimer t(p, K_OTHER);
+        launch_finalize(s, dp);
+    }
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -619,6 +693,22 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     return PT_OK;
 }
 
+int pt_pass_set_profiling(pt_pass *pass, int enable) {
+    if(!pass) return fail(PT_ERR_INVALID, "pt_pass_set_profiling: null pass");
+    pass->profiling = enable != 0;
+    return PT_OK;
+}
+
+int pt_pass_profile(pt_pass *pass, pt_profile *out, int reset) {
+    if(!pass || !out) return fail(PT_ERR_INVALID, "pt_pass_profile: null argument");
+    HIP_TRY(hipSetDevice(pass->ctx->device));
+    HIP_TRY(hipStreamSynchronize(pass->ctx->stream));
+    collect_profile(pass);
+    *out = pass->prof;
+    if(reset) memset(&pass->prof, 0, sizeof pass->prof);
+    return PT_OK;
+}
+
 int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
     if(!p || !rays || !hits) return fail(PT_ERR_INVALID, "pt_pass_intersect: null argument");
     if(rays->ctx != p->ctx || hits->ctx != p->ctx) return fail(PT_ERR_INVALID, "pt_pass_intersect: buffers belong to another context");
@@ -637,8 +727,11 @@ int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
     const TraceScene sc = make_trace_scene(p);
     long long blocks = ((long long)n + TRACE_BLOCK - 1) / TRACE_BLOCK;
     if(blocks > p->trace_blocks) blocks = p->trace_blocks;
-    launch_intersect(s, sc, (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n,
-                     static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT);
+    {
+        ScopedTimer t(p, K_INTERSECT);
+        launch_intersect(s, sc, (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n,
+                         static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT);
+    }
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }

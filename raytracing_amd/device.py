@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import PtStats, check, lib
+from ._capi import PtProfile, PtStats, check, lib
 
 HIT_DTYPE = np.dtype([("instance", "<i4"), ("triangle", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
 
@@ -196,6 +196,14 @@ class PathTracingPass:
         check(lib.pt_pass_stats(self.h, C.byref(s), int(reset)))
         return dict(samples=int(s.samples), rays_extend=int(s.rays_extend), rays_shadow=int(s.rays_shadow),
                     draws=int(s.draws))
+
+    def set_profiling(self, enable=True):
+        check(lib.pt_pass_set_profiling(self.h, int(enable)))
+
+    def profile(self, reset=False):
+        pr = PtProfile()
+        check(lib.pt_pass_profile(self.h, C.byref(pr), int(reset)))
+        return {n: getattr(pr, n) for n, _ in PtProfile._fields_}
 
     def download(self):
         out = {}

@@ -1,0 +1,52 @@
+"""Sample slicing across GPUs.
+
+The reference is single-GPU; what it defines is the per-pixel running mean over the
+samples of a frame (shader/pathtracing.glsl:657-670).  Samples are independent, so G
+ranks each hold the whole scene and render a disjoint slice of the global sample
+indices 1..SPP; seeds and jitter are functions of the GLOBAL index, so the set of
+samples -- and therefore the image up to fp32 summation order -- does not depend on G.
+Each rank accumulates plain sums (pt_params.accum_mode = 1); one all-reduce(sum) over the
+nine accumulated floats per pixel and a division by SPP finish the frame.  The four
+last-write outputs (motion, depth, normal, instanceIndex) are taken from the rank that
+rendered the last sample, which is what a single GPU would have left in them.
+
+The functions here take the collective backend as arguments so that the same logic runs
+over RCCL on GPUs and over gloo on CPUs (tests).
+"""
+import numpy as np
+
+ACCUMULATED = ("directLum", "indirectLum", "albedo")
+LAST_WRITE = ("motion", "depth", "normal", "instanceIndex")
+CHANNELS = {"directLum": 3, "indirectLum": 3, "albedo": 3, "motion": 2, "depth": 1, "normal": 3, "instanceIndex": 1}
+
+
+def sample_slice(total_spp, rank, world):
+    """1-based global sample indices rendered by `rank`: s with (s - 1) % world == rank."""
+    return list(range(1 + rank, total_spp + 1, world))
+
+
+def owner_of_last_sample(total_spp, world):
+    return (total_spp - 1) % world
+
+
+def combine(dist, tensors, total_spp, world, torch):
+    """tensors: dict name -> flat float32 tensor holding this rank's sums (ACCUMULATED) and
+    last-write values (LAST_WRITE).  In place: afterwards every rank holds the frame."""
+    owner = owner_of_last_sample(total_spp, world)
+    for name in ACCUMULATED:
+        dist.all_reduce(tensors[name], op=dist.ReduceOp.SUM)
+        tensors[name].mul_(1.0 / float(total_spp))
+    for name in LAST_WRITE:
+        dist.broadcast(tensors[name], src=owner)
+    return tensors
+
+
+def allreduce_outputs(torch, dist, pass_, npix, total_spp, dev_tensor):
+    """GPU form: wraps the pass's output buffers as torch tensors (no copy) and combines
+    them over the default process group (RCCL)."""
+    world = dist.get_world_size()
+    tensors = {}
+    for name, c in CHANNELS.items():
+        tensors[name] = dev_tensor(torch, pass_.outputs[name].device_ptr, npix * c)
+    combine(dist, tensors, total_spp, world, torch)
+    torch.cuda.synchronize()

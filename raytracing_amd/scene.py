@@ -396,6 +396,96 @@ def procedural_sky(width=2048, height=1024):
     return Sky.from_hdr_bytes(rgbe_encode(procedural_sky_rgb(width, height)))
 
 
+def random_rays(lo, hi, n, seed):
+    """Incoherent test rays: origins uniform in the box [lo, hi], directions uniform on the
+    sphere (z = 2u - 1, phi = 2 pi u'), from numpy's PCG64 seeded with `seed`; (n, 6) float32."""
+    rng = np.random.default_rng(seed)
+    o = lo + (hi - lo) * rng.random((n, 3))
+    z = 2 * rng.random(n) - 1
+    ph = 2 * np.pi * rng.random(n)
+    r = np.sqrt(np.maximum(0.0, 1 - z * z))
+    d = np.stack([r * np.cos(ph), r * np.sin(ph), z], 1)
+    return np.concatenate([o, d], 1).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# synthetic large scene
+# --------------------------------------------------------------------------------------
+def _grid_mesh(pos, nu, nv, uv_scale=1.0):
+    """Triangulates an (nu+1) x (nv+1) vertex grid; smooth vertex normals from the faces."""
+    pos = pos.astype(np.float32)
+    iu, iv = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    a = (iu * (nv + 1) + iv).ravel()
+    b = a + (nv + 1)
+    c = b + 1
+    d = a + 1
+    idx = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)], 0)
+    P = pos.reshape(-1, 3)
+    fn = np.cross(P[idx[:, 1]] - P[idx[:, 0]], P[idx[:, 2]] - P[idx[:, 0]])
+    vn = np.zeros_like(P)
+    for k in range(3):
+        np.add.at(vn, idx[:, k], fn)
+    vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-20)
+    gu, gv = np.meshgrid(np.arange(nu + 1) / nu, np.arange(nv + 1) / nv, indexing="ij")
+    UV = (np.stack([gu, gv], -1).reshape(-1, 2) * uv_scale).astype(np.float32)
+    tri = np.concatenate([P[idx].reshape(-1, 9), vn[idx].reshape(-1, 9), UV[idx].reshape(-1, 6)], 1)
+    return np.ascontiguousarray(tri, np.float32)
+
+
+def synthetic_scene(n_tris=10_000_000, n_threads=0, seed=12345, dielectric_fraction=0.0):
+    """Procedural stand-in for the large configurations: a 4 x 4 tiling of displaced terrain
+    patches and 48 displaced spheres resting above it, 64 meshes / 64 instances in all,
+    about n_tris triangles, conductor materials with seeded roughness 0.05..0.8 (a
+    fraction may be rough dielectrics).  Deterministic for a given (n_tris, seed)."""
+    rng = np.random.default_rng(seed)
+    per_mesh = max(8, n_tris // 64)
+    k = max(2, int(round(math.sqrt(per_mesh / 2.0))))
+    b = SceneBuilder()
+    tile = 20.0
+
+    def material():
+        t = 2 if rng.random() < dielectric_fraction else 1
+        return dict(type=t, albedo=tuple(np.float32(0.2 + 0.75 * rng.random(3))),
+                    roughness=np.float32(0.05 + 0.75 * rng.random()),
+                    metallic=np.float32(1.0 if rng.random() < 0.5 else 0.0), tex=-1,
+                    ior=np.float32(1.3 + 0.5 * rng.random()))
+
+    def height(x, z):
+        return (1.5 * np.sin(0.21 * x) * np.cos(0.17 * z) + 0.6 * np.sin(0.53 * x + 1.3) * np.sin(0.47 * z + 0.4)
+                + 0.15 * np.sin(2.1 * x) * np.cos(1.9 * z))
+
+    for ti in range(4):
+        for tj in range(4):
+            u = np.linspace(0, tile, k + 1)
+            x, z = np.meshgrid(u + (ti - 2) * tile, u + (tj - 2) * tile, indexing="ij")
+            y = height(x, z)
+            # mesh-local coordinates are relative to the tile corner; the instance translates
+            pos = np.stack([x - (ti - 2) * tile, y, z - (tj - 2) * tile], -1)
+            m = b.add_mesh(_grid_mesh(pos, k, k, 4.0))
+            b.add_instance(m, transform_matrix(((ti - 2) * tile, 0, (tj - 2) * tile)), material())
+    ku = max(2, int(round(math.sqrt(per_mesh))))   # ku x (ku/2) quads x 2
+    kv = max(2, ku // 2)
+    for s in range(48):
+        th = np.linspace(0, 2 * np.pi, ku + 1)
+        ph = np.linspace(0.02, np.pi - 0.02, kv + 1)
+        T, Pp = np.meshgrid(th, ph, indexing="ij")
+        f1, f2, a1 = 3 + rng.integers(0, 6), 2 + rng.integers(0, 5), 0.05 + 0.15 * rng.random()
+        rad = 1.0 + a1 * np.sin(f1 * T) * np.sin(f2 * Pp)
+        pos = np.stack([rad * np.sin(Pp) * np.cos(T), rad * np.cos(Pp), rad * np.sin(Pp) * np.sin(T)], -1)
+        m = b.add_mesh(_grid_mesh(pos, ku, kv, 1.0))
+        cx, cz = (rng.random(2) * 4 - 2) * tile * 0.9
+        scale = 1.5 + 3.0 * rng.random()
+        cy = float(height(cx, cz)) + scale * (0.9 + 1.5 * rng.random())
+        rot = tuple(rng.random(3) * 360.0)
+        b.add_instance(m, transform_matrix((cx, cy, cz), rot, (scale, scale, scale)), material())
+    return b.finish(n_threads)
+
+
+def synthetic_camera():
+    """Elevated view across the synthetic scene."""
+    return transform_matrix((-34.0, 16.0, 38.0), (-20.0, -42.0, 0.0), (1, 1, 1))
+
+
 # --------------------------------------------------------------------------------------
 # per-draw parameters
 # --------------------------------------------------------------------------------------

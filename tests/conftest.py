@@ -52,11 +52,5 @@ def gpu_ctx():
 
 
 def random_rays(lo, hi, n, seed):
-    """Origins uniform in the box, directions uniform on the sphere (z = 2u-1, phi = 2 pi u')."""
-    rng = np.random.default_rng(seed)
-    o = lo + (hi - lo) * rng.random((n, 3))
-    z = 2 * rng.random(n) - 1
-    ph = 2 * np.pi * rng.random(n)
-    r = np.sqrt(np.maximum(0.0, 1 - z * z))
-    d = np.stack([r * np.cos(ph), r * np.sin(ph), z], 1)
-    return np.concatenate([o, d], 1).astype(np.float32)
+    from raytracing_amd import scene
+    return scene.random_rays(lo, hi, n, seed)
