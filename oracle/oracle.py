@@ -208,13 +208,12 @@ def ref_mat_inverse(mats):
     return raw[:len(mats) * 16].reshape(-1, 16), raw[len(mats) * 16:]
 
 
-def ref_hdr_decode(hdr_bytes):
+def ref_rgbe_component_table():
+    """convertComponent(exponent byte - 128, mantissa byte) of include/hdrloader.cpp for all
+    256 x 256 inputs (the loader's entry point itself is not runnable on LP64)."""
     with tempfile.TemporaryDirectory() as d:
-        open(d + "/i.hdr", "wb").write(hdr_bytes)
-        subprocess.check_call([REF_HARNESS, "hdr", d + "/i.hdr", d + "/o.bin"])
-        raw = open(d + "/o.bin", "rb").read()
-    w, h = struct.unpack_from("<ii", raw, 0)
-    return np.frombuffer(raw, np.float32, w * h * 3, 8).reshape(h, w, 3).copy()
+        subprocess.check_call([REF_HARNESS, "hdr", d + "/o.bin"])
+        return np.fromfile(d + "/o.bin", np.float32).reshape(256, 256)
 
 
 def ref_stb_decode(image_bytes):

@@ -8,7 +8,7 @@
 //   include/hdrloader.cpp  include/stb_image.cpp
 // and links them with this driver into oracle/_ref/ref_harness.  Everything
 // numerical (SAH build, std::sort tie order, slab / Moller-Trumbore tests, RGBE
-// decode, JPEG decode, glm::inverse) is executed by reference code; this file only
+// component conversion, JPEG decode, glm::inverse) is executed by reference code; this file only
 // moves bytes in and out and restates the two GL-entangled loops that cannot be
 // compiled headless:
 //   - Mesh::build_meshBVH            (src/instance/Mesh.cpp:10-22)
@@ -180,12 +180,19 @@ static int cmd_mat(const char *in, const char *out) {
     return 0;
 }
 
-static int cmd_hdr(const char *in, const char *out) {
-    HDRLoaderResult res; res.width = res.height = 0; res.cols = nullptr;
-    if(!HDRLoader::load(in, res)) { fprintf(stderr, "HDRLoader::load failed\n"); return 1; }
+// HDRLoader::load itself cannot be driven on LP64: it reads the resolution with
+// sscanf("%ld") into two ints (include/hdrloader.cpp:67-68), which overwrites one of them.
+// Its arithmetic lives in convertComponent(expo, val) (hdrloader.cpp:99-104), which has
+// external linkage; dump it for every exponent byte and mantissa byte.
+//   out: f32 table[256 exponent bytes][256 mantissa bytes]  (expo = byte - 128)
+float convertComponent(int expo, int val);
+static int cmd_hdr(const char *out) {
     FILE *f = fopen(out, "wb");
-    fwrite(&res.width, 4, 1, f); fwrite(&res.height, 4, 1, f);
-    fwrite(res.cols, 4, (size_t)res.width * res.height * 3, f);
+    for(int e = 0; e < 256; e++)
+        for(int v = 0; v < 256; v++) {
+            float x = convertComponent(e - 128, v);
+            fwrite(&x, 4, 1, f);
+        }
     fclose(f);
     return 0;
 }
@@ -210,9 +217,9 @@ int main(int argc, char **argv) {
     if(c == "bvh" && argc == 4) return cmd_bvh(argv[2], argv[3]);
     if(c == "isect" && argc == 6) return cmd_isect(argv[2], argv[3], argv[4], argv[5]);
     if(c == "mat" && argc == 4) return cmd_mat(argv[2], argv[3]);
-    if(c == "hdr" && argc == 4) return cmd_hdr(argv[2], argv[3]);
+    if(c == "hdr" && argc == 3) return cmd_hdr(argv[2]);
     if(c == "stb" && argc == 4) return cmd_stb(argv[2], argv[3]);
     fprintf(stderr, "usage: ref_harness bvh <meshes> <out> | isect <meshes> <scene> <rays> <out> | "
-                    "mat <in> <out> | hdr <file.hdr> <out> | stb <image> <out>\n");
+                    "mat <in> <out> | hdr <out> | stb <image> <out>\n");
     return 2;
 }

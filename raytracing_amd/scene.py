@@ -16,6 +16,7 @@ import ctypes as C
 import io
 import json
 import math
+import os
 import struct
 
 import numpy as np
@@ -205,7 +206,7 @@ def _accessor(js, blob, idx):
     return np.array(a)
 
 
-def decode_image(data):
+def decode_image(data, index=0):
     """Decodes an embedded image to uint8 (h, w, c), rows top to bottom, channels as
     stored -- what stbi_load_from_memory(..., 0) returns in loader.cpp:23-27."""
     from PIL import Image  # Pillow ships in the image; libjpeg's IDCT may differ from stb_image's by +-1..2 levels
@@ -257,7 +258,7 @@ def load_glb(path, image_decoder=decode_image):
             img = js["images"][src]
             bv = js["bufferViews"][img["bufferView"]]
             raw = blob[bv.get("byteOffset", 0): bv.get("byteOffset", 0) + bv["byteLength"]]
-            textures.append(image_decoder(raw))
+            textures.append(image_decoder(raw, src))
             mat["tex"] = len(textures) - 1
         materials.append(mat)
 
@@ -306,8 +307,21 @@ def load_glb(path, image_decoder=decode_image):
     return meshes, materials, textures, instances
 
 
-def casa_scene(glb_path, n_threads=0, image_decoder=decode_image):
-    """The demo scene of main.cpp:380-383: casa_obj.glb under a root rotated (-90, 0, 0)."""
+def casa_scene(glb_path, n_threads=0, image_decoder=None):
+    """The demo scene of main.cpp:380-383: casa_obj.glb under a root rotated (-90, 0, 0).
+
+    The embedded JPEG is taken from casa_textures.npz next to the .glb when that file
+    exists: it holds the pixels the reference's own decoder (stb_image) produces, which
+    differ from libjpeg's by a level or two in places."""
+    if image_decoder is None:
+        npz = os.path.join(os.path.dirname(os.path.abspath(glb_path)), "casa_textures.npz")
+        if os.path.exists(npz):
+            stored = np.load(npz)
+
+            def image_decoder(raw, index):
+                return np.ascontiguousarray(stored["image%d" % index])
+        else:
+            image_decoder = decode_image
     meshes, materials, textures, instances = load_glb(glb_path, image_decoder)
     b = SceneBuilder()
     for t in textures:

@@ -1,0 +1,208 @@
+"""Host-side scene layer against the compiled reference (golden fixtures made by
+tests/golden/make_golden.py, and live when oracle/_ref exists)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CASA, GOLDEN
+
+
+def test_casa_load_matches_the_survey(casa):
+    assert len(casa.tri_count) == 19 and int(casa.tri_count.sum()) == 34689
+    assert len(casa.instances) == 19 and len(casa.mesh_nodes) == 69359 and len(casa.scene_nodes) == 37
+    assert len(casa.textures) == 1 and casa.textures[0].shape == (256, 512, 3)
+    assert casa.mesh_depth.max() == 20
+    # every casa material becomes a conductor with metallic = 1 (loader.cpp:44-65)
+    assert np.all(casa.materials[0::7] == 1.0) and np.all(casa.materials[5::7] == 1.0)
+    assert casa.materials[4::7].min() == np.float32(0.001)
+    assert (casa.materials[6::7] >= 0).sum() == 1
+
+
+def test_casa_mesh_bvh_bit_exact_with_reference_build(casa):
+    g = json.load(open(os.path.join(GOLDEN, "casa_bvh.json")))
+    raw = casa.mesh_nodes.tobytes()
+    assert hashlib.sha256(casa.triangles.tobytes()).hexdigest() == g["triangles_sha256"]
+    assert len(casa.mesh_nodes) == g["n_nodes"]
+    assert list(raw[:48 * 8]) == g["first_nodes"] and list(raw[-48 * 8:]) == g["last_nodes"]
+    assert hashlib.sha256(raw).hexdigest() == g["mesh_nodes_sha256"]
+    assert [int(x) for x in casa.mesh_siz] == g["siz"] and [int(x) for x in casa.mesh_depth] == g["depth"]
+
+
+def _build(tri_count, triangles, threads=4):
+    from raytracing_amd import scene
+    b = scene.SceneBuilder()
+    base = 0
+    for n in tri_count:
+        m = b.add_mesh(triangles[base:base + n])
+        b.add_instance(m)
+        base += int(n)
+    return b.finish(threads)
+
+
+def test_sort_ties_follow_the_reference(casa):
+    g = np.load(os.path.join(GOLDEN, "synth_meshes.npz"))
+    sd = _build(g["tri_count"], g["triangles"])
+    assert np.array_equal(np.frombuffer(sd.mesh_nodes.tobytes(), np.uint8), g["nodes"])
+    assert np.array_equal(sd.mesh_siz, g["siz"]) and np.array_equal(sd.mesh_depth, g["depth"])
+    # single-threaded and multi-threaded builds agree
+    sd1 = _build(g["tri_count"], g["triangles"], threads=1)
+    assert sd1.mesh_nodes.tobytes() == sd.mesh_nodes.tobytes()
+
+
+def test_flatten_invariants(casa):
+    n = casa.mesh_nodes
+    nm = len(casa.tri_count)
+    inner = n["tri"] < 0
+    # roots first, children numbered after their parent, in pairs, breadth first
+    assert np.all(n["ls"][inner] > np.nonzero(inner)[0]) and np.all(n["rs"][inner] == n["ls"][inner] + 1)
+    assert np.all(n["ls"][~inner] == -1) and np.all(n["inst"] == -1)
+    kids = np.sort(np.concatenate([n["ls"][inner], n["rs"][inner]]))
+    assert np.array_equal(kids, np.arange(nm, len(n)))
+    assert np.array_equal(np.sort(n["tri"][~inner]), np.arange(casa.tri_count.sum()))
+    s = casa.scene_nodes
+    leaf = s["inst"] >= 0
+    assert np.array_equal(np.sort(s["inst"][leaf]), np.arange(len(casa.instances)))
+    assert np.all(s["ls"][leaf] == -1) and np.all(s["tri"] == -1)
+    assert casa.bvh_siz == int(casa.mesh_siz.sum()) + int((~leaf).sum())
+
+
+def test_live_against_compiled_reference(casa, oracle_mod):
+    if not oracle_mod.have_ref():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(3)
+    tris = np.zeros((3000, 24), np.float32)
+    tris[:, :9] = (rng.integers(0, 12, (3000, 1, 3)) + rng.integers(0, 3, (3000, 3, 3)) * 0.5).reshape(3000, 9)
+    sd = _build(np.array([1000, 2000], np.int32), tris)
+    nodes, siz, depth = oracle_mod.ref_mesh_bvh(sd)
+    assert np.array_equal(np.frombuffer(sd.mesh_nodes.tobytes(), np.uint8), nodes)
+    assert np.array_equal(siz, sd.mesh_siz) and np.array_equal(depth, sd.mesh_depth)
+
+
+def test_glm_inverse_and_product_bit_exact():
+    from raytracing_amd import scene
+    g = np.load(os.path.join(GOLDEN, "glm_mat.npz"))
+    prod = np.eye(4, dtype=np.float32).reshape(16)
+    for m, inv in zip(g["mats"], g["inverse"]):
+        assert np.array_equal(scene.mat4_inverse(m).view(np.uint32), inv.view(np.uint32))
+        prod = scene.mat4_mul(prod, m)
+    assert np.array_equal(prod.view(np.uint32), g["product"].view(np.uint32))
+
+
+def test_transform_matrix_matches_a_double_precision_trs():
+    from raytracing_amd import scene
+    pos, rot, scl = (1.5, -2.0, 3.25), (30.0, -45.0, 60.0), (2.0, 0.5, 1.5)
+    m = scene.transform_matrix(pos, rot, scl).reshape(4, 4).T.astype(np.float64)   # rows/cols
+    x, y, z = np.radians(rot)
+    rx = np.array([[1, 0, 0], [0, np.cos(x), -np.sin(x)], [0, np.sin(x), np.cos(x)]])
+    ry = np.array([[np.cos(y), 0, np.sin(y)], [0, 1, 0], [-np.sin(y), 0, np.cos(y)]])
+    rz = np.array([[np.cos(z), -np.sin(z), 0], [np.sin(z), np.cos(z), 0], [0, 0, 1]])
+    ref = ry @ rx @ rz @ np.diag(scl)      # order string "YXZ", then scale (Transform.cpp:43-50)
+    assert np.allclose(m[:3, :3], ref, atol=1e-6) and np.allclose(m[:3, 3], pos) and np.allclose(m[3], [0, 0, 0, 1])
+    assert np.array_equal(scene.transform_matrix(), np.eye(4, dtype=np.float32).reshape(16))
+
+
+def test_instance_info_and_world_boxes(casa):
+    from raytracing_amd import scene
+    for i in (0, 7, 18):
+        inv = scene.mat4_inverse(casa.l2w[i])
+        assert np.array_equal(casa.instances["w2l"][i].view(np.uint32), inv.view(np.uint32))
+        assert casa.instances["meshIndex"][i] == i and casa.instances["materialPtr"][i] == 7 * i
+    # scene leaf boxes = bounds of the 8 transformed corners of the mesh root box
+    s = casa.scene_nodes
+    for k in np.nonzero(s["inst"] >= 0)[0][:5]:
+        i = s["inst"][k]
+        lo, hi = casa.mesh_root_box[i][:3], casa.mesh_root_box[i][3:]
+        m = casa.l2w[i].reshape(4, 4).T.astype(np.float64)
+        c = np.array([[(lo, hi)[(b >> a) & 1][a] for a in range(3)] + [1.0] for b in range(8)])
+        w = (m @ c.T).T[:, :3]
+        assert np.allclose(s["aa"][k][:3], w.min(0), atol=1e-4) and np.allclose(s["bb"][k][:3], w.max(0), atol=1e-4)
+
+
+def test_rgbe_decode_matches_reference_loader():
+    """Every (mantissa, exponent) byte pair decodes to what the reference's
+    convertComponent gives (include/hdrloader.cpp:99-104)."""
+    from raytracing_amd import scene
+    table = np.load(os.path.join(GOLDEN, "rgbe_components.npz"))["table"]
+    w, h = 256, 256
+    px = np.zeros((h, w, 4), np.uint8)
+    px[..., 0] = np.arange(w)[None, :]            # mantissa sweeps along x
+    px[..., 1] = 255 - np.arange(w)[None, :]
+    px[..., 2] = (np.arange(w)[None, :] * 7) % 256
+    px[..., 3] = np.arange(h)[:, None]            # exponent byte sweeps along y
+    px[:, 0, 0] = 3                               # keep (2,2,x) RLE markers out of column 0
+    data = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + px.tobytes()
+    sky = scene.Sky.from_hdr_bytes(data)
+    e = np.arange(h)[:, None]
+    for c in range(3):
+        exp = table[e, px[..., c]]
+        assert np.array_equal(sky.rgb[..., c].view(np.uint32), exp.view(np.uint32))
+    # encode -> decode is idempotent after the first quantisation
+    q = scene.Sky.from_hdr_bytes(scene.rgbe_encode(scene.procedural_sky_rgb(64, 32)))
+    again = scene.Sky.from_hdr_bytes(scene.rgbe_encode(q.rgb))
+    assert np.array_equal(again.rgb, q.rgb)
+
+
+def test_rgbe_rle_scanlines():
+    """New-style run-length encoded scanlines (what real .hdr files use)."""
+    from raytracing_amd import scene
+    w, h = 16, 3
+    px = np.zeros((h, w, 4), np.uint8)
+    px[..., 0] = np.arange(w)[None, :] * 3
+    px[..., 1] = 77
+    px[..., 2] = np.arange(h)[:, None] * 40
+    px[..., 3] = 129
+    body = bytearray()
+    for y in range(h):
+        body += bytes([2, 2, 0, w])
+        for c in range(4):
+            row = px[y, :, c]
+            if len(set(row)) == 1:
+                body += bytes([128 + w, int(row[0])])
+            else:
+                body += bytes([w]) + bytes(int(v) for v in row)
+    data = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + bytes(body)
+    sky = scene.Sky.from_hdr_bytes(data)
+    exp = px[..., :3].astype(np.float32) / 256.0 * 2.0
+    assert np.array_equal(sky.rgb, exp)
+
+
+def test_rgbe_rejects_garbage():
+    from raytracing_amd import scene, _capi
+    with pytest.raises(_capi.PtError):
+        scene.Sky.from_hdr_bytes(b"not a radiance file at all.....")
+    with pytest.raises(_capi.PtError):
+        scene.Sky.from_hdr_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 4 +X 4\n\x01\x02")
+
+
+def test_sky_cache_follows_the_cdf(small_sky):
+    """Independent numpy restatement of src/texture/Skybox.cpp:12-53."""
+    rgb = small_sky.rgb.astype(np.float64)
+    h, w = rgb.shape[:2]
+    pdf = rgb[..., 0] * 0.2 + rgb[..., 1] * 0.7 + rgb[..., 2] * 0.1
+    light_sum = 0.0
+    for v in pdf.ravel():      # sequential double accumulation, as the reference does
+        light_sum += v
+    assert small_sky.light_sum == light_sum
+    spdf = np.cumsum(pdf, axis=1)
+    FY = np.cumsum(spdf[:, -1])
+    for (i, j) in [(0, 0), (3, 17), (h // 2, w // 2), (h - 1, w - 1), (h - 1, 0), (17, w - 1)]:
+        u = float(np.float32(i) / np.float32(h))
+        v = float(np.float32(j) / np.float32(w))
+        Y = int(np.searchsorted(FY, u * light_sum, side="left"))
+        X = int(np.searchsorted(spdf[Y], v * spdf[Y][w - 1], side="left"))
+        exp = (np.float32(X) / np.float32(w), np.float32(Y) / np.float32(h), np.float32(pdf[Y, X] / light_sum))
+        assert tuple(small_sky.cache[i, j]) == exp
+    # the cache integrates to one: sum of pdf over the texels it points at, weighted uniformly
+    assert abs(pdf.sum() / light_sum - 1.0) < 1e-9
+
+
+def test_mt19937_jitter_sequence():
+    from raytracing_amd import scene
+    j = scene.mt19937_jitters(3)
+    # first outputs of std::mt19937 seeded with 0: 2357136044, 2546248239, 3071714933, 3626093760
+    assert abs(j[0][0] - 2357136044 / 4294967295) < 1e-7 and abs(j[0][1] - 2546248239 / 4294967295) < 1e-7
+    assert abs(j[1][0] - 3071714933 / 4294967295) < 1e-7
+    assert j[2] == (0.5, 0.5)

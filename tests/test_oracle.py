@@ -1,0 +1,297 @@
+"""Pins the oracle (oracle/pt_oracle.cpp) itself, on the CPU:
+
+  - closest hits against the reference's own compiled CPU picking routine (golden fixture
+    from tests/golden/make_golden.py, and live when oracle/_ref exists);
+  - the Sobol sampler against an independent evaluation of the direction table;
+  - BSDF / sky / texture formulas against float64 transcriptions written here from the GLSL;
+  - its own 64x36 render against the committed regression image.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def test_closest_hit_equals_reference_picking(casa, oracle_mod):
+    g = np.load(os.path.join(GOLDEN, "casa_rays.npz"))
+    hits, cnt = oracle_mod.OracleScene(casa).intersect(g["rays"])
+    assert (g["triangle"] >= 0).sum() > 900
+    # The shader accepts t >= 0.001, u, v >= 0, u + v <= 1 where the CPU routine is strict,
+    # starts the slab interval at 0 instead of -inf and visits children in the other order;
+    # none of that changes a generic ray's answer: ids and t are bit-identical.
+    assert np.array_equal(hits["triangle"], g["triangle"])
+    assert np.array_equal(hits["instance"], g["instance"])
+    assert np.array_equal(hits["t"].view(np.uint32), g["t"].view(np.uint32))
+    assert cnt["rays"] == len(g["rays"]) and cnt["max_stack"] <= 64
+
+
+def test_closest_hit_live_against_compiled_reference(casa, oracle_mod):
+    if not oracle_mod.have_ref():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    from raytracing_amd import scene
+    lo, hi = casa.world_box()
+    rays = scene.random_rays(lo, hi, 50000, 1234)
+    hits, _ = oracle_mod.OracleScene(casa).intersect(rays)
+    ref = oracle_mod.ref_intersect(casa, rays)
+    assert np.array_equal(hits["triangle"], ref["triangle"]) and np.array_equal(hits["instance"], ref["instance"])
+    assert np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32))
+
+
+def test_traversal_work_matches_the_survey_probe(casa, oracle_mod):
+    from raytracing_amd import scene
+    lo, hi = casa.world_box()
+    rays = scene.random_rays(lo, hi, 200000, 7)
+    hits, cnt = oracle_mod.OracleScene(casa).intersect(rays)
+    n = len(rays)
+    assert 0.24 < cnt["hits"] / n < 0.28
+    assert 5.0 < cnt["scene_nodes"] / n < 6.0 and 13.0 < cnt["mesh_inner_nodes"] / n < 15.0
+    assert 1.0e3 < oracle_mod.algorithmic_bytes_per_ray(cnt) < 1.2e3
+
+
+def _table():
+    txt = open(os.path.join(ROOT, "oracle", "sobol_table.inc")).read()
+    import re
+    vals = [int(x) for x in re.findall(r"(\d+)u,", txt)]
+    assert len(vals) == 640
+    return vals
+
+
+def test_sobol_against_independent_evaluation(oracle_mod):
+    lib = oracle_mod.lib()
+    V = _table()
+    for d in (0, 1, 2, 7, 19):
+        for i in (0, 1, 2, 3, 12345, 0xFFFFFFFF, 0x80000001, 26699 | 1):
+            r = 0
+            for j in range(32):
+                if (i >> j) & 1:
+                    r ^= V[d * 32 + j]
+            exp = np.float32(np.float32(r) * np.float32(2.0 ** -32))
+            assert np.float32(lib.orc_sobol(d, i)) == exp
+    # dimension 0 is the van der Corput sequence; the value 1.0 is reachable (float(r) rounds up)
+    assert lib.orc_sobol(0, 1) == 0.5 and lib.orc_sobol(0, 3) == 0.75
+    assert lib.orc_sobol(1, 0xFFFFFFFF) <= 1.0
+    # beyond the table: the documented folding, and distinct from the row it reuses
+    def wang(s):
+        s = ((s ^ 61) ^ (s >> 16)) & 0xFFFFFFFF
+        s = (s * 9) & 0xFFFFFFFF
+        s = s ^ (s >> 4)
+        s = (s * 0x27d4eb2d) & 0xFFFFFFFF
+        return s ^ (s >> 15)
+    for d in (20, 21, 38, 39, 57):
+        i = 777
+        fold, dd = (d - 1) // 19, 1 + (d - 1) % 19
+        assert lib.orc_sobol(d, i) == lib.orc_sobol(dd, wang((i + 0x9E3779B9 * fold) & 0xFFFFFFFF))
+
+
+def _material_scene(oracle_mod, stream):
+    s = oracle_mod.OrcScene()
+    arr = np.array(stream, np.float32)
+    s.materials = arr.ctypes.data
+    return s, arr
+
+
+def _call_material(oracle_mod, sc, which, mptr, wi, wo, seed=1, dim=1, n=8):
+    out = (C.c_float * n)()
+    f3 = lambda v: (C.c_float * 3)(*v)
+    oracle_mod.lib().orc_material(C.byref(sc), which, mptr, f3(wi), f3(wo), (C.c_float * 2)(0.25, 0.75), seed, dim, out)
+    return np.array(out[:], np.float64)
+
+
+PI = 3.1415926   # the reference's truncated constant (shader/basic/math.glsl:2)
+
+
+def _ggx_D(a, hz):
+    c = abs(hz)
+    return a * a * c / ((c * c * (a * a - 1) + 1) ** 2) / PI
+
+
+def _conductor_eval(albedo, a, metallic, wi, wo):
+    wi, wo = np.array(wi, float), np.array(wo, float)
+    if np.sign(wi[2]) != np.sign(wo[2]):
+        return np.zeros(3)
+    F0 = 0.04 * (1 - metallic) + np.array(albedo) * metallic
+    H = wi + wo
+    H /= np.linalg.norm(H)
+    H *= np.sign(H[2])
+    OdotH = abs(wo @ H)
+    On, In = abs(wo[2]), abs(wi[2])
+    F = F0 + (1 - F0) * (1 - OdotH) ** 5
+    k = (a + 1) ** 2 / 8
+    G = 0.25 / ((In * (1 - k) + k) * (On * (1 - k) + k))
+    Fd90 = 0.5 + 2 * OdotH ** 2 * a
+    Fd = (1 + (Fd90 - 1) * (1 - In) ** 5) * (1 + (Fd90 - 1) * (1 - On) ** 5)
+    return _ggx_D(a, H[2]) * F * G + (1 - metallic) * np.array(albedo) * Fd * 0.3183098
+
+
+def test_conductor_formulas(oracle_mod):
+    """shader/materials/RoughConductor.glsl:3-59 re-derived in float64."""
+    albedo, a, metallic = (0.8, 0.5, 0.3), 0.35, 0.6
+    sc, keep = _material_scene(oracle_mod, [1.0, *albedo, a, metallic, -1.0])
+    wi = np.array([0.3, -0.2, 0.9]); wi /= np.linalg.norm(wi)
+    wo = np.array([-0.4, 0.1, 0.7]); wo /= np.linalg.norm(wo)
+    got = _call_material(oracle_mod, sc, 0, 0, wi, wo)[:3]
+    assert np.allclose(got, _conductor_eval(albedo, a, metallic, wi, wo), rtol=2e-5)
+    H = (wi + wo) / np.linalg.norm(wi + wo)
+    pdf = _call_material(oracle_mod, sc, 1, 0, wi, wo)[0]
+    assert np.isclose(pdf, _ggx_D(a, H[2]) / (4 * abs(wo @ H)), rtol=2e-5)
+    # opposite hemispheres: no reflection
+    assert np.all(_call_material(oracle_mod, sc, 0, 0, wi, [0.1, 0.2, -0.9])[:3] == 0)
+    assert _call_material(oracle_mod, sc, 1, 0, wi, [0.1, 0.2, -0.9])[0] == 0
+    # sample: wo is the mirror of wi about a GGX half vector; value = eval(wi, wo); pdf = D/(4 o.h)
+    s = _call_material(oracle_mod, sc, 2, 0, wi, [0, 0, 0], seed=4242, dim=3)
+    val, spdf, swo, eta = s[:3], s[3], s[4:7], s[7]
+    assert eta == 1.0 and abs(np.linalg.norm(swo) - 1) < 1e-5
+    if spdf > 0:
+        Hs = (wi + swo) / np.linalg.norm(wi + swo)
+        assert np.isclose(spdf, _ggx_D(a, Hs[2]) / (4 * abs(swo @ Hs)), rtol=1e-3)
+        assert np.allclose(val, _conductor_eval(albedo, a, metallic, wi, swo), rtol=1e-3)
+    # albedo without a texture map is the constant colour; unknown material types give zeros
+    assert np.allclose(_call_material(oracle_mod, sc, 3, 0, wi, wo)[:3], albedo, rtol=1e-7)
+    sc2, keep2 = _material_scene(oracle_mod, [5.0, *albedo, a, metallic, -1.0])
+    assert np.all(_call_material(oracle_mod, sc2, 0, 0, wi, wo)[:3] == 0)
+    assert _call_material(oracle_mod, sc2, 2, 0, wi, wo)[3] == -1.0
+
+
+def _fresnel(cosI, eta):
+    cosI = abs(cosI)
+    sinT = 1 / eta * np.sqrt(max(0.0, 1 - cosI * cosI))
+    if sinT > 1:
+        return 1.0
+    cosT = np.sqrt(1 - sinT * sinT)
+    Rs = ((cosI - eta * cosT) / (cosI + eta * cosT)) ** 2
+    Rp = ((cosT - eta * cosI) / (cosT + eta * cosI)) ** 2
+    return (Rs + Rp) / 2
+
+
+def test_dielectric_formulas(oracle_mod):
+    """shader/materials/RoughDielectric.glsl:7-76 re-derived in float64 (reflection and
+    transmission lobes, wi on either side)."""
+    albedo, a, ior = (0.9, 0.95, 1.0), 0.2, 1.5
+    sc, keep = _material_scene(oracle_mod, [2.0, *albedo, a, 0.0, -1.0, ior])
+    G1 = lambda c: c / (c * (1 - (a + 1) ** 2 / 8) + (a + 1) ** 2 / 8)
+    for wi, wo in [((0.2, 0.1, 0.97), (-0.3, 0.2, 0.93)), ((0.2, 0.1, 0.97), (-0.15, -0.1, -0.98)),
+                   ((0.1, -0.3, -0.95), (0.05, 0.2, 0.97))]:
+        wi = np.array(wi) / np.linalg.norm(wi)
+        wo = np.array(wo) / np.linalg.norm(wo)
+        eta = ior if wi[2] >= 0 else 1 / ior
+        refl = np.sign(wi[2]) == np.sign(wo[2])
+        H = wi + wo if refl else -(wi + eta * wo)
+        H = H / np.linalg.norm(H) if refl else H / np.linalg.norm(wi + eta * wo)
+        D, F = _ggx_D(a, H[2]), _fresnel(wi @ H, eta)
+        G = G1(abs(wi[2])) * G1(abs(wo[2]))
+        if np.sign(wi @ H) != np.sign(wi[2]) or np.sign(wo @ H) != np.sign(wo[2]):
+            G = 0.0
+        if refl:
+            exp = np.array(albedo) * F * D * G / abs(4 * wi[2] * wo[2])
+            epdf = D * F / abs(4 * (wi @ H))
+        else:
+            den = (wi @ H + eta * (wo @ H)) ** 2
+            exp = np.array(albedo) * abs((1 - F) * D * G * (wi @ H) * (wo @ H) / (wi[2] * wo[2] * den))
+            epdf = D * (1 - F) * eta * eta * abs(wo @ H) / den
+        assert np.allclose(_call_material(oracle_mod, sc, 0, 0, wi, wo)[:3], exp, rtol=5e-5, atol=1e-9)
+        assert np.isclose(_call_material(oracle_mod, sc, 1, 0, wi, wo)[0], epdf, rtol=5e-5)
+    # sampling consumes a third random number and sets eta on transmission
+    seen = set()
+    wi_s = np.array([0.3, 0.1, 0.95]) / np.linalg.norm([0.3, 0.1, 0.95])
+    for seed in range(1, 400, 7):
+        s = _call_material(oracle_mod, sc, 2, 0, wi_s, (0, 0, 0), seed=seed, dim=1)
+        if s[3] > 0:
+            seen.add(round(float(s[7]), 4))
+            assert abs(np.linalg.norm(s[4:7]) - 1) < 1e-4
+    assert seen == {1.0, 1.5}
+
+
+def test_texture_filter_is_gl_bilinear_repeat(oracle_mod):
+    rng = np.random.default_rng(0)
+    px = rng.integers(0, 256, (4, 8, 3), dtype=np.uint8)
+    tx = oracle_mod.OrcTexture()
+    tx.data = px.ctypes.data
+    tx.height, tx.width, tx.channels, tx.format = 4, 8, 3, 0
+    out = (C.c_float * 4)()
+
+    def fetch(s, t):
+        oracle_mod.lib().orc_texture_fetch(C.byref(tx), C.c_float(s), C.c_float(t), out)
+        return np.array(out[:3])
+
+    texel = px.astype(np.float64) / 255
+    # texel centres return the texel; REPEAT wraps whole periods and negative coordinates
+    assert np.allclose(fetch((2 + 0.5) / 8, (1 + 0.5) / 4), texel[1, 2], atol=1e-6)
+    assert np.allclose(fetch((2 + 0.5) / 8 + 3, (1 + 0.5) / 4 - 2), texel[1, 2], atol=1e-6)
+    # halfway between two texels, and across the wrap seam
+    assert np.allclose(fetch(3.0 / 8, 1.5 / 4), (texel[1, 2] + texel[1, 3]) / 2, atol=1e-6)
+    assert np.allclose(fetch(0.0, 0.5 / 4), (texel[0, 7] + texel[0, 0]) / 2, atol=1e-6)
+    assert np.allclose(fetch(0.0, 0.0), (texel[0, 7] + texel[0, 0] + texel[3, 7] + texel[3, 0]) / 4, atol=1e-6)
+
+
+def test_sky_lookup_and_importance_sampling(casa, small_sky, oracle_mod):
+    from raytracing_amd import scene
+    osc = oracle_mod.OracleScene(casa, small_sky)
+    prm = scene.make_params(8, 8, scene.casa_camera(), small_sky)
+    lib = oracle_mod.lib()
+    out3 = (C.c_float * 3)()
+    # equirectangular lookup (pathtracing.glsl:370-377) re-derived in float64: row 0 of the
+    # picture is the zenith, u = atan(z, x) / 2pi + 1/2, bilinear with REPEAT wrap
+    H, W = small_sky.rgb.shape[:2]
+    img = small_sky.rgb.astype(np.float64)
+    for d in ([0.5, 0.5, 0.7071], [-0.3, 0.1, -0.9], [0.2, -0.6, 0.3], [0.9, 0.43, 0.05]):
+        d = np.array(d) / np.linalg.norm(d)
+        u = np.arctan2(d[2], d[0]) / (2 * PI) + 0.5
+        v = 1.0 - (np.arcsin(d[1]) / PI + 0.5)
+        x, y = u * W - 0.5, v * H - 0.5
+        x0, y0 = int(np.floor(x)), int(np.floor(y))
+        a, b = x - x0, y - y0
+        t = lambda i, j: img[j % H, i % W]
+        exp = (1 - a) * (1 - b) * t(x0, y0) + a * (1 - b) * t(x0 + 1, y0) + (1 - a) * b * t(x0, y0 + 1) + a * b * t(x0 + 1, y0 + 1)
+        lib.orc_background(C.byref(osc.c), (C.c_float * 3)(*d), out3)
+        assert np.allclose(out3[:], exp, rtol=2e-3)
+    # the sampled direction's pdf equals the pdf the lookup reports for that direction
+    # (up to the bilinear blur of both), and samples concentrate on the sun
+    out4 = (C.c_float * 4)()
+    sun_hits = 0
+    for seed in range(1, 2000, 13):
+        lib.orc_skybox_sample(C.byref(osc.c), C.byref(prm), seed, 1, out4)
+        w, pdf = np.array(out4[:3]), out4[3]
+        assert abs(np.linalg.norm(w) - 1) < 1e-5 and pdf >= 0
+        lib.orc_background(C.byref(osc.c), (C.c_float * 3)(*w), out3)
+        if max(out3[:]) > 50:
+            sun_hits += 1
+    assert sun_hits > 20   # the sun covers ~0.1 % of the sphere but most of the energy
+
+
+def test_render_regression_image(casa, small_sky, oracle_mod):
+    from raytracing_amd import scene
+    g = np.load(os.path.join(GOLDEN, "oracle_image.npz"))
+    gc = json.load(open(os.path.join(GOLDEN, "oracle_image_counters.json")))
+    prm = scene.make_params(64, 36, scene.casa_camera(), small_sky, spp=1, max_depth=2)
+    out, cnt = oracle_mod.OracleScene(casa, small_sky).render(prm)
+    for k in g.files:
+        a, b = out[k], g[k]
+        assert np.all((a.view(np.uint32) == b.view(np.uint32)) | (a == b) | (np.isnan(a) & np.isnan(b))), k
+    for k, v in gc.items():
+        assert cnt[k] == v
+    # sanity of the image itself: both hits and sky, finite radiance, unit normals
+    hit = out["instanceIndex"][..., 0] >= 0
+    assert 0.2 < hit.mean() < 0.95
+    assert np.isfinite(out["directLum"]).all() and np.isfinite(out["indirectLum"]).all()
+    assert np.allclose(np.linalg.norm(out["normal"][hit], axis=-1), 1, atol=1e-4)
+    assert np.all(out["depth"][~hit] == 1e6) and np.all(out["normal"][~hit] == [0, 0, 1])
+
+
+def test_running_mean_and_sum_accumulation(casa, small_sky, oracle_mod):
+    from raytracing_amd import scene
+    osc = oracle_mod.OracleScene(casa, small_sky)
+    v2w = scene.casa_camera()
+    singles, mean, total = [], None, None
+    for s in (1, 2, 3):
+        prm1 = scene.make_params(32, 18, v2w, small_sky, spp=1, frame=s, max_depth=2)   # same seed as (frame 1, spp s)
+        singles.append(osc.render(prm1)[0])
+        mean = osc.render(scene.make_params(32, 18, v2w, small_sky, spp=s, frame=1, max_depth=2), mean)[0]
+        total = osc.render(scene.make_params(32, 18, v2w, small_sky, spp=s, frame=1, max_depth=2, accum_mode=1), total)[0]
+    for k in ("directLum", "indirectLum", "albedo"):
+        exp = sum(x[k].astype(np.float64) for x in singles)
+        assert np.allclose(total[k], exp, rtol=1e-5, atol=1e-6)
+        assert np.allclose(mean[k], exp / 3, rtol=1e-5, atol=1e-6)
