@@ -157,6 +157,13 @@ typedef struct pt_stats {
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 
+/* Traversal strategy; no counterpart in the reference.
+ *   0 (default) ordered traversal (nearer child first, reciprocal-direction culling,
+ *     batched leaves); rays whose two closest hits lie within 2e-4 of each other are traced
+ *     again in the reference's order, so results are those of mode 1;
+ *   1 the reference's visiting order for every ray (shader/pathtracing.glsl:254-316). */
+int pt_pass_set_traversal(pt_pass *pass, int mode);
+
 /* Per-kernel device time, measured with HIP events recorded on the context's stream around
  * every launch while profiling is enabled.  No counterpart in the reference (its only
  * timing is an FPS counter, main.cpp:423-435); used by bench.py for the roofline figure. */

@@ -7,6 +7,7 @@
 #include <vector>
 #include "capi_common.h"
 #include "device/kernels.h"
+#include "device/trace_fast.h"
 #include "host/accel_layout.h"
 #include "host/scene_types.h"
 
@@ -48,8 +49,10 @@ constexpr int MAX_PATH_DEPTH = 64;
 constexpr int CNT_QUEUE = 0;       // [0, 70): paths alive per vertex
 constexpr int CNT_SHADOW = 70;     // [70, 140): paths with pending light samples per vertex
 constexpr int CNT_NEXT = 140;      // [140, 280): next-ray counters, two per vertex
-constexpr int CNT_INTERSECT = 280;
-constexpr int CNT_TOTAL = 288;
+constexpr int CNT_REDO = 280;       // [280, 350): rays the ordered extend handed to the reference-order extend
+constexpr int CNT_NEXT_REDO = 350;  // [350, 420): next-ray counters of those launches
+constexpr int CNT_INTERSECT = 420;  // next-ray, redo count, next-ray of the redo launch
+constexpr int CNT_TOTAL = 432;
 
 struct DeviceArray {
     void *p = nullptr;
@@ -90,7 +93,9 @@ struct pt_pass {
     // derived scene
     bool accel_valid = false;
     AccelHost accel_info;  // header + sizes (vectors are cleared after upload)
-    DeviceArray d_mesh_nodes, d_scene_nodes, d_tri_pos, d_inst, d_spill, d_tex_table;
+    DeviceArray d_mesh_nodes, d_scene_nodes, d_tri_pos, d_tri_leaf, d_inst, d_spill, d_tex_table;
+    DeviceArray d_queue_r, d_redo_isect;  // redo lists of the ordered extend / intersect
+    int traversal_mode = 0;               // 0 ordered + exact fallback, 1 reference order only
     int n_textures = 0;
     int spill_depth = 0;
     size_t n_material_floats = 0;
@@ -98,6 +103,7 @@ struct pt_pass {
     DeviceArray d_rays, d_hits, d_thr, d_acc, d_shadow, d_queue_a, d_queue_b, d_queue_s, d_counters, d_stats, d_err;
     int shadow_capacity = 0;
     int trace_blocks = 0;
+    int redo_blocks = 0;  // grid of the (small) reference-order launches behind the ordered ones
     // optional per-kernel timing
     bool profiling = false;
     struct Timed { int kind; hipEvent_t a, b; };
@@ -182,10 +188,11 @@ int prepare_scene(pt_pass *p) {
             if((rc = upload_array(ctx, p->d_mesh_nodes, ah.mesh_nodes.data(), ah.mesh_nodes.size() * sizeof(TNode)))) return rc;
             if((rc = upload_array(ctx, p->d_scene_nodes, ah.scene_nodes.data(), ah.scene_nodes.size() * sizeof(TNode)))) return rc;
             if((rc = upload_array(ctx, p->d_tri_pos, ah.tri_pos.data(), ah.tri_pos.size() * sizeof(TriPos)))) return rc;
+            if((rc = upload_array(ctx, p->d_tri_leaf, ah.tri_leaf.data(), ah.tri_leaf.size() * sizeof(TLeaf)))) return rc;
             if((rc = upload_array(ctx, p->d_inst, ah.instances.data(), ah.instances.size() * sizeof(InstAccel)))) return rc;
             p->accel_info.header = ah.header;
             p->accel_info.max_stack = ah.max_stack;
-            int need = ah.max_stack + 2 - LDS_STACK;
+            int need = ah.max_stack + 2 - (LDS_STACK < FAST_LDS_STACK ? LDS_STACK : FAST_LDS_STACK);
             if(need < 0) need = 0;
             if(need > p->spill_depth || !p->d_spill.p) {
                 p->spill_depth = need < 4 ? 4 : need;
@@ -290,6 +297,19 @@ void collect_profile(pt_pass *p) {
         p->event_pool.push_back(t.b);
     }
     p->timed.clear();
+}
+
+FastScene make_fast_scene(pt_pass *p) {
+    FastScene sc;
+    sc.mesh_nodes = static_cast<const TNode *>(p->d_mesh_nodes.p);
+    sc.scene_nodes = static_cast<const TNode *>(p->d_scene_nodes.p);
+    sc.tri_leaf = static_cast<const TLeaf *>(p->d_tri_leaf.p);
+    sc.inst = static_cast<const InstAccel *>(p->d_inst.p);
+    sc.hdr = p->accel_info.header;
+    sc.spill = static_cast<uint2 *>(p->d_spill.p);
+    sc.spill_depth = p->spill_depth;
+    sc.error_flag = static_cast<unsigned *>(p->d_err.p);
+    return sc;
 }
 
 TexDesc desc_of(const pt_tex *t) {
@@ -493,7 +513,8 @@ int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
     int rc = PT_OK;
     for(int k = 0; k < 7 && !rc; k++) rc = pt_buf_create(ctx, npix * OUT_CHANNELS[k] * sizeof(float), nullptr, &p->outputs[k]);
     // 6 blocks of 256 threads per CU: 24 KiB of LDS stack each, 24 waves per CU
-    p->trace_blocks = ctx->num_cus * 6;
+    p->trace_blocks = ctx->num_cus * 8;
+    p->redo_blocks = ctx->num_cus;
     if(!rc) rc = p->d_rays.ensure(npix * sizeof(PathRay));
     if(!rc) rc = p->d_hits.ensure(npix * sizeof(PathHit));
     if(!rc) rc = p->d_thr.ensure(npix * sizeof(PathThroughput));
@@ -501,6 +522,7 @@ int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
     if(!rc) rc = p->d_queue_a.ensure(npix * 4);
     if(!rc) rc = p->d_queue_b.ensure(npix * 4);
     if(!rc) rc = p->d_queue_s.ensure(npix * 4);
+    if(!rc) rc = p->d_queue_r.ensure(npix * 4);
     if(!rc) rc = p->d_counters.ensure(CNT_TOTAL * 4);
     if(!rc) rc = p->d_stats.ensure(8 * 8);
     if(!rc) rc = p->d_err.ensure(16);
@@ -525,7 +547,7 @@ int pt_pass_destroy(pt_pass *p) {
     for(int k = 0; k < 7; k++) pt_buf_release(p->outputs[k]);
     collect_profile(p);
     for(hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
-    DeviceArray *arrs[] = {&p->d_mesh_nodes, &p->d_scene_nodes, &p->d_tri_pos, &p->d_inst, &p->d_spill, &p->d_tex_table,
+    DeviceArray *arrs[] = {&p->d_mesh_nodes, &p->d_scene_nodes, &p->d_tri_pos, &p->d_tri_leaf, &p->d_queue_r, &p->d_redo_isect, &p->d_inst, &p->d_spill, &p->d_tex_table,
                            &p->d_rays, &p->d_hits, &p->d_thr, &p->d_acc, &p->d_shadow, &p->d_queue_a, &p->d_queue_b,
                            &p->d_queue_s, &p->d_counters, &p->d_stats, &p->d_err};
     for(DeviceArray *a : arrs) a->release();
@@ -625,6 +647,9 @@ int pt_pass_draw(pt_pass *p) {
 
     hipStream_t s = ctx->stream;
     const TraceScene sc = make_trace_scene(p);
+    const FastScene fsc = make_fast_scene(p);
+    const bool ordered = p->traversal_mode == 0;
+    unsigned *qr = static_cast<unsigned *>(p->d_queue_r.p);
     HIP_TRY(hipMemsetAsync(cnt, 0, CNT_TOTAL * 4, s));
     {
         ScopedTimer t(p, K_OTHER);
@@ -637,7 +662,14 @@ int pt_pass_draw(pt_pass *p) {
         unsigned *q_out = (dep & 1) ? qb : qa;
         {
             ScopedTimer t(p, K_EXTEND);
-            launch_extend(s, sc, p->trace_blocks, q_in, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
+            if(ordered) {
+                launch_extend_fast(s, fsc, p->trace_blocks, q_in, cnt + CNT_QUEUE + dep, dp.rays, dp.hits,
+                                   cnt + CNT_NEXT + 2 * dep, qr, cnt + CNT_REDO + dep);
+                // near-ties in t: decided by the reference-order traversal
+                launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep);
+            } else {
+                launch_extend(s, sc, p->trace_blocks, q_in, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
+            }
         }
         {
             ScopedTimer t(p, K_SHADE);
@@ -646,8 +678,12 @@ int pt_pass_draw(pt_pass *p) {
         if(dep < P.MAX_DEPTH) {
             {
                 ScopedTimer t(p, K_SHADOW);
-                launch_shadow(s, sc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
-                              cnt + CNT_NEXT + 2 * dep + 1);
+                if(ordered && n_shadow == 1)
+                    launch_shadow_fast(s, fsc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, (int)npix,
+                                       cnt + CNT_NEXT + 2 * dep + 1);
+                else
+                    launch_shadow(s, sc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
+                                  cnt + CNT_NEXT + 2 * dep + 1);
             }
             ScopedTimer t(p, K_OTHER);
             launch_shadow_apply(s, dp, qs, cnt + CNT_SHADOW + dep);
@@ -693,6 +729,13 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     return PT_OK;
 }
 
+int pt_pass_set_traversal(pt_pass *pass, int mode) {
+    if(!pass) return fail(PT_ERR_INVALID, "pt_pass_set_traversal: null pass");
+    if(mode != 0 && mode != 1) return fail(PT_ERR_INVALID, "pt_pass_set_traversal: mode must be 0 (ordered) or 1 (reference order)");
+    pass->traversal_mode = mode;
+    return PT_OK;
+}
+
 int pt_pass_set_profiling(pt_pass *pass, int enable) {
     if(!pass) return fail(PT_ERR_INVALID, "pt_pass_set_profiling: null pass");
     pass->profiling = enable != 0;
@@ -723,14 +766,23 @@ int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
     if(n == 0) return PT_OK;
     unsigned *cnt = static_cast<unsigned *>(p->d_counters.p);
     hipStream_t s = p->ctx->stream;
-    HIP_TRY(hipMemsetAsync(cnt + CNT_INTERSECT, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(cnt + CNT_INTERSECT, 0, 12, s));
     const TraceScene sc = make_trace_scene(p);
+    if(p->traversal_mode == 0 && (rc = p->d_redo_isect.ensure(n * 4))) return rc;
     long long blocks = ((long long)n + TRACE_BLOCK - 1) / TRACE_BLOCK;
     if(blocks > p->trace_blocks) blocks = p->trace_blocks;
     {
         ScopedTimer t(p, K_INTERSECT);
-        launch_intersect(s, sc, (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n,
-                         static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT);
+        if(p->traversal_mode == 0) {
+            unsigned *redo = static_cast<unsigned *>(p->d_redo_isect.p);
+            launch_intersect_fast(s, make_fast_scene(p), (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n,
+                                  static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT, redo, cnt + CNT_INTERSECT + 1);
+            launch_intersect(s, sc, p->redo_blocks, static_cast<const float *>(rays->dptr), (unsigned)n, redo,
+                             cnt + CNT_INTERSECT + 1, static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT + 2);
+        } else {
+            launch_intersect(s, sc, (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n, nullptr, nullptr,
+                             static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT);
+        }
     }
     HIP_TRY(hipGetLastError());
     return PT_OK;

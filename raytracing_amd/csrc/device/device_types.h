@@ -39,21 +39,37 @@ struct alignas(16) TriPos {
 };
 static_assert(sizeof(TriPos) == 48, "triangle position record is 48 bytes");
 
-// Per-instance record, 96 bytes.  row[r] = (m[0][r], m[1][r], m[2][r], m[3][r]) of the
-// column-major world-to-local matrix, i.e. local = row . (world, 1).
-struct alignas(16) InstAccel {
-    float row[3][4];
-    float root_lo[3], root_hi[3];  // box of the mesh root (tested in local space)
-    uint32_t root_ref;             // mesh root: inner node or, for a 1-triangle mesh, the triangle
-    int32_t material_ptr;
-    uint32_t pad[4];
+// Triangle leaf of the ordered traversal, 64 bytes: the exact fp32 box of the leaf's PARENT
+// node in the reference tree (the last box the reference tests before it tests the
+// triangle; +-inf when the triangle is the whole mesh) followed by v0, e1, e2.
+struct alignas(64) TLeaf {
+    float parent_lo[3], parent_hi[3];
+    float v0[3];
+    float e1[3];
+    float e2[3];
+    float pad;
 };
-static_assert(sizeof(InstAccel) == 96, "instance record is 96 bytes");
+static_assert(sizeof(TLeaf) == 64, "triangle leaf record is 64 bytes");
+
+// Per-instance record, 128 bytes.  row[r] = (m[0][r], m[1][r], m[2][r], m[3][r]) of the
+// column-major world-to-local matrix, i.e. local = row . (world, 1).  The first 64 bytes are
+// all a ray needs to enter the instance.
+struct alignas(64) InstAccel {
+    float row[3][4];
+    uint32_t root_ref;               // mesh root: inner node or, for a 1-triangle mesh, the triangle
+    int32_t material_ptr;
+    uint32_t pad0[2];
+    float root_lo[3], root_hi[3];    // box of the mesh root (tested in local space)
+    float world_lo[3], world_hi[3];  // box of the instance's scene-level leaf (tested in world space)
+    uint32_t pad1[4];
+};
+static_assert(sizeof(InstAccel) == 128, "instance record is 128 bytes");
 
 struct SceneHeader {
     float root_lo[3], root_hi[3];  // box of scene node 0
     uint32_t root_ref;             // scene inner node 0, or the only instance
     uint32_t n_instances;
+    float extent;                  // |x| + |y| + |z| extent of the scene box (scales absolute tolerances)
 };
 
 // ---- closest-hit record (matches pt_hit in the public header, padded to 32 B in the

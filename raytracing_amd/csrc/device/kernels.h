@@ -37,19 +37,27 @@ struct DrawParams {
     unsigned *counters;
 };
 
-struct LaunchGeom {
-    int blocks;  // persistent trace grid
-};
+struct FastScene;
 
-// closest hit for n rays given as 6 floats each; hits as pt_hit records
-void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n, pt_hit *hits,
-                      unsigned *next_counter);
+// closest hit for n rays given as 6 floats each; hits as pt_hit records.  With redo != nullptr
+// only the rays listed there (count read from *redo_count) are traced.
+void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n,
+                      const unsigned *redo, const unsigned *redo_count, pt_hit *hits, unsigned *next_counter);
+// ordered form: undecided rays are appended to redo instead of being written
+void launch_intersect_fast(hipStream_t s, const FastScene &sc, int blocks, const float *rays, unsigned n,
+                           pt_hit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count);
 // extend stage: rays[queue[q]] -> hits[queue[q]] for q < *count (queue == nullptr: q itself)
 void launch_extend(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                    const PathRay *rays, PathHit *hits, unsigned *next_counter);
+void launch_extend_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                        const PathRay *rays, PathHit *hits, unsigned *next_counter, unsigned *redo,
+                        unsigned *redo_count);
 // shadow stage: ray (q, k) for q < *count, k < n_shadow; marks visible entries
 void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                    const PathRay *rays, ShadowEntry *shadow, int n_shadow, int npix, unsigned *next_counter);
+// sky-only (n_shadow == 1) ordered form
+void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                        const PathRay *rays, ShadowEntry *shadow, int npix, unsigned *next_counter);
 
 void launch_generate(hipStream_t s, const DrawParams &dp);
 // shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to

@@ -59,9 +59,49 @@ __device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float
     return tmx >= tmi && tmx >= RT_RAY_MINDIS;
 }
 
+
+// Ray indices are handed out per WAVE in batches: one returning atomic on the shared
+// counter per batch instead of one per lane-refill.  A single counter word sustains only
+// ~88 returning atomics per microsecond chip-wide; drawing single indices made that the
+// bottleneck of every trace launch (16 Mi rays / ~24 lanes per refill = 0.7 M atomics = 8 ms).
+struct WaveRayFeed {
+    unsigned base = 0, left = 0;  // wave-uniform: next index of the current batch, indices left in it
+    bool dry = false;             // wave-uniform: the counter has passed n_rays
+    unsigned batch;
+    __device__ explicit WaveRayFeed(unsigned n_rays) {
+        // enough batches for every wave of the launch to get several; at least one ray per lane
+        const unsigned waves = gridDim.x * (blockDim.x / 64u);
+        unsigned b = n_rays / (waves * 4u + 1u);
+        b = b < 64u ? 64u : (b > 1024u ? 1024u : b);
+        batch = b & ~63u;
+    }
+    // Every lane of the wave must call this together.  Returns true and sets idx for lanes
+    // that asked for a ray and got one; lanes that asked but got none ask again next time.
+    __device__ bool take(bool want, unsigned *next_ray, unsigned n_rays, unsigned &idx) {
+        const unsigned long long m = __ballot(want);
+        if(m == 0ull) return false;
+        if(left == 0u && !dry) {
+            unsigned b = 0;
+            if((threadIdx.x & 63u) == 0u) b = atomicAdd(next_ray, batch);
+            b = __builtin_amdgcn_readfirstlane(b);
+            base = b;
+            left = b < n_rays ? (n_rays - b < batch ? n_rays - b : batch) : 0u;
+            dry = left == 0u;
+        }
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const bool got = want && rank < left;
+        idx = base + rank;
+        const unsigned asked = (unsigned)__popcll(m);
+        const unsigned taken = asked < left ? asked : left;
+        base += taken;
+        left -= taken;
+        return got;
+    }
+};
+
 // Persistent-wave traversal.  Every lane owns one ray at a time; a lane whose ray is
-// finished takes the next ray index from *next_ray (one atomic per lane, merged per wave
-// by the compiler) as soon as fewer than REFILL_BELOW lanes of its wave are still busy,
+// finished takes the next ray index (WaveRayFeed) as soon as fewer than REFILL_BELOW lanes
+// of its wave are still busy,
 // so long rays do not hold 63 idle lanes hostage.  Every wave leaves the loop once the
 // counter has passed n_rays and its own lanes are done.
 //
@@ -76,6 +116,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
 
     bool active = false, have = false, exhausted = false, any_hit = false;
+    WaveRayFeed feed(n_rays);
     unsigned ray_idx = 0;
     int sp = 0;
     float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;  // world-space ray
@@ -87,9 +128,9 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
     float tn = 0;
 
     for(;;) {
-        if(!active && !exhausted) {
-            unsigned idx = atomicAdd(next_ray, 1u);
-            if(idx < n_rays) {
+        {
+            unsigned idx = 0;
+            if(feed.take(!active, next_ray, n_rays, idx)) {
                 float o[3], d[3];
                 bool ah = false;
                 if(src.load(idx, o, d, ah)) {
@@ -106,9 +147,8 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                     ref = sc.hdr.root_ref;
                     tn = t0;
                 }
-            } else {
-                exhausted = true;
             }
+            exhausted = feed.dry;
         }
         if(!__any(active)) {
             if(__all(exhausted)) break;
@@ -162,7 +202,8 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
             } else if(kind == REF_INSTANCE) {
                 // entry into intersect_meshBVH, shader/pathtracing.glsl:254-264
                 const float4 *ip = reinterpret_cast<const float4 *>(sc.inst + idx);
-                const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], bx0 = ip[3], bx1 = ip[4];
+                // rows, (root_ref, material), root box: lo.xyz hi.x | hi.yz ..
+                const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], rr = ip[3], bx0 = ip[4], bx1 = ip[5];
                 lox = (r0.x * wox + r0.y * woy) + (r0.z * woz + r0.w);
                 loy = (r1.x * wox + r1.y * woy) + (r1.z * woz + r1.w);
                 loz = (r2.x * wox + r2.y * woy) + (r2.z * woz + r2.w);
@@ -170,7 +211,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                 ldy = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
                 ldz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
                 cur_inst = (int)idx;
-                ref = __float_as_uint(bx1.z);
+                ref = __float_as_uint(rr.x);
                 if((ref >> 30) != REF_TRIANGLE) {
                     float t0;
                     have = slab_test(bx0.x, bx0.y, bx0.z, bx0.w, bx1.x, bx1.y, lox, loy, loz, ldx, ldy, ldz, t0);

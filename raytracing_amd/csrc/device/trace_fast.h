@@ -1,0 +1,274 @@
+// Ordered closest-hit / occlusion traversal: the fast path.
+//
+// What the reference's traversal (shader/pathtracing.glsl:254-316) returns can be stated
+// without its visiting order.  Call a triangle a CANDIDATE of a ray when the reference's
+// box tests pass on every node above it; because a child's box lies inside its parent's
+// and fp32 subtraction and division are monotone, that is the case exactly when the box of
+// the triangle's parent node passes (in the instance's space) and the box of the
+// instance's scene leaf passes (in world space).  The reference returns the candidate hit
+// with the smallest t -- unless its order-dependent prune `tnear > t_best` discarded that
+// winner's subtree, which needs another candidate hit whose t lies between the winner's t
+// and the entry distance of the winner's own parent box: a near-tie in t (shared edges,
+// coplanar duplicates), since the two differ only by rounding.
+//
+// So this kernel is free to visit nodes in any order and to cull with cheaper arithmetic,
+// as long as
+//   (1) culling is conservative: boxes are tested with a per-ray reciprocal and the
+//       comparisons are relaxed by 1e-6, eight times the arithmetic's error;
+//   (2) a hit is accepted only for a candidate: the parent box (and, where a scene node
+//       hands over to an instance, the scene leaf box) is re-tested with the reference's
+//       exact IEEE-division slab test whenever the relaxed test did not pass with the same
+//       margin to spare;
+//   (3) subtrees are pruned only beyond t_best * (1 + 1e-3) (+ an absolute term scaled by
+//       the scene size), so every hit inside the near-tie band is seen;
+//   (4) the smallest t among all OTHER hits is tracked, and a ray whose runner-up lies
+//       within 2e-4 of the winner is reported as ambiguous: the caller re-traces it with
+//       the reference-order kernel (trace_core.h), which is exact by construction.
+// The triangle test itself is the reference's Moller-Trumbore, bit for bit.
+// Occlusion queries ("is there any candidate hit") have no order dependence at all.
+//
+// Loop shape: the kernel is bound by the latency of dependent gathers, not by arithmetic,
+// so every lane issues exactly ONE 64-byte fetch per iteration, whatever it is about to
+// visit (inner node, triangle leaf and instance record are all 64-byte records), the wave
+// waits once, and only then the three kinds are told apart.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.h"
+#include "trace_core.h"
+
+namespace rta {
+
+constexpr int FAST_BLOCK = 256;
+constexpr int FAST_LDS_STACK = 8;  // 8-byte entries per lane in LDS: 16 KiB per block
+
+struct FastScene {
+    const TNode *mesh_nodes;
+    const TNode *scene_nodes;
+    const TLeaf *tri_leaf;
+    const InstAccel *inst;
+    SceneHeader hdr;
+    uint2 *spill;
+    int spill_depth;
+    unsigned *error_flag;
+};
+
+// relaxed slab test with a reciprocal direction; tn = entry distance (>= 0)
+__device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float hix, float hiy, float hiz, float ox,
+                                          float oy, float oz, float ix, float iy, float iz, float &tn, bool &clear) {
+    const float t1x = (lox - ox) * ix, t2x = (hix - ox) * ix;
+    const float t1y = (loy - oy) * iy, t2y = (hiy - oy) * iy;
+    const float t1z = (loz - oz) * iz, t2z = (hiz - oz) * iz;
+    float tmi = fmaxf(fmaxf(0.0f, fminf(t1x, t2x)), fmaxf(fminf(t1y, t2y), fminf(t1z, t2z)));
+    float tmx = fminf(fminf(RT_INF, fmaxf(t1x, t2x)), fminf(fmaxf(t1y, t2y), fmaxf(t1z, t2z)));
+    tn = tmi;
+    const float up = tmx * 1.000001f, dn = tmx * 0.999999f;
+    clear = dn >= tmi * 1.000001f && dn >= 0.001001f;
+    return up >= tmi * 0.999999f && up >= RT_RAY_MINDIS;
+}
+
+// Source: bool load(unsigned idx, float o[3], float d[3], bool &any_hit)
+// Sink:   void store(unsigned idx, const LaneHit &h, bool ambiguous)
+template <class Source, class Sink>
+__device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, Sink &sink, unsigned *next_ray,
+                                              unsigned n_rays, uint2 *s_stack) {
+    constexpr int REFILL_BELOW = 40;  // refill when fewer lanes than this still own a ray
+    const unsigned tid = threadIdx.x;
+    const unsigned gtid = blockIdx.x * blockDim.x + tid;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+
+    bool active = false, have = false, exhausted = false, any_hit = false;
+    WaveRayFeed feed(n_rays);
+    unsigned ray_idx = 0;
+    int sp = 0;
+    float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;  // world ray
+    float cox = 0, coy = 0, coz = 0, cdx = 0, cdy = 0, cdz = 0;  // ray in the current space
+    float cix = 0, ciy = 0, ciz = 0;                             // 1 / direction in the current space
+    bool in_mesh = false;
+    LaneHit best;
+    best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
+    float second_t = RT_INF, abs_slack = 0.0f;
+    int cur_inst = -1;
+    unsigned ref = 0;
+    float tn = 0;
+
+    for(;;) {
+        {
+            unsigned idx = 0;
+            if(feed.take(!active, next_ray, n_rays, idx)) {
+                float o[3], d[3];
+                bool ah = false;
+                if(src.load(idx, o, d, ah)) {
+                    ray_idx = idx;
+                    any_hit = ah;
+                    wox = o[0]; woy = o[1]; woz = o[2];
+                    wdx = d[0]; wdy = d[1]; wdz = d[2];
+                    cox = wox; coy = woy; coz = woz;
+                    cdx = wdx; cdy = wdy; cdz = wdz;
+                    cix = 1.0f / wdx; ciy = 1.0f / wdy; ciz = 1.0f / wdz;
+                    in_mesh = false;
+                    best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
+                    second_t = RT_INF;
+                    abs_slack = 1e-6f * (fabsf(wox) + fabsf(woy) + fabsf(woz) + sc.hdr.extent);
+                    active = true;
+                    sp = 0;
+                    // the scene root's box, exactly (once per ray): it is the scene leaf box
+                    // itself when the scene is a single instance
+                    float t0;
+                    have = slab_test(sc.hdr.root_lo[0], sc.hdr.root_lo[1], sc.hdr.root_lo[2], sc.hdr.root_hi[0],
+                                     sc.hdr.root_hi[1], sc.hdr.root_hi[2], wox, woy, woz, wdx, wdy, wdz, t0);
+                    ref = sc.hdr.root_ref;
+                    tn = t0;
+                }
+            }
+            exhausted = feed.dry;
+        }
+        if(!__any(active)) {
+            if(__all(exhausted)) break;
+            continue;
+        }
+        const bool drained = __any(exhausted);
+
+        for(;;) {
+            // ---- take the next deferred entry that is still worth visiting, or finish the ray
+            const float prune_t = best.t * 1.001f + 8.0f * abs_slack;
+            while(active && !have) {
+                if(sp > 0) {
+                    --sp;
+                    const uint2 e = sp < FAST_LDS_STACK ? s_stack[sp * FAST_BLOCK + tid]
+                                                        : sc.spill[(size_t)(sp - FAST_LDS_STACK) * nthreads + gtid];
+                    ref = e.x;
+                    tn = __uint_as_float(e.y);
+                    have = !(tn > prune_t);  // it may have fallen behind the closest hit meanwhile
+                } else {
+                    const bool ambiguous = !any_hit && best.tri >= 0 && second_t <= best.t * 1.0002f + 2.0f * abs_slack;
+                    sink.store(ray_idx, best, ambiguous);
+                    active = false;
+                }
+            }
+            const int nact = __popcll(__ballot(active));
+            if(nact == 0) break;
+            if(!drained && nact < REFILL_BELOW) break;
+
+            // ---- one 64-byte fetch per lane, whatever the entry is
+            const unsigned kind = ref >> 30, idx = ref & REF_INDEX_MASK;
+            float4 q0, q1, q2, q3;
+            if(have) {
+                const char *base = kind == REF_MESH_INNER    ? reinterpret_cast<const char *>(sc.mesh_nodes + idx)
+                                   : kind == REF_TRIANGLE    ? reinterpret_cast<const char *>(sc.tri_leaf + idx)
+                                   : kind == REF_SCENE_INNER ? reinterpret_cast<const char *>(sc.scene_nodes + idx)
+                                                             : reinterpret_cast<const char *>(sc.inst + idx);
+                const float4 *rp = reinterpret_cast<const float4 *>(base);
+                q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3];
+            } else {
+                q0 = q1 = q2 = q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            // scene-level entries are met with the world ray
+            if(have && kind >= REF_SCENE_INNER && in_mesh) {
+                cox = wox; coy = woy; coz = woz;
+                cdx = wdx; cdy = wdy; cdz = wdz;
+                cix = 1.0f / wdx; ciy = 1.0f / wdy; ciz = 1.0f / wdz;
+                in_mesh = false;
+            }
+
+            if(have && (kind == REF_MESH_INNER || kind == REF_SCENE_INNER)) {
+                float t0, t1;
+                bool c0clear, c1clear;
+                bool p0 = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, c0clear);
+                bool p1 = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cix, ciy, ciz, t1, c1clear);
+                const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                const unsigned k0 = c0 >> 30, k1 = c1 >> 30;
+                // a triangle child has no box of its own: it inherits this node's fate, which
+                // the exact parent-box test at the leaf settles; order it by this node's entry
+                if(k0 == REF_TRIANGLE) { p0 = true; t0 = tn; }
+                if(k1 == REF_TRIANGLE) { p1 = true; t1 = tn; }
+                // an instance child: its box is the scene leaf box, whose EXACT test decides
+                // whether anything inside the instance is a candidate
+                if(k0 == REF_INSTANCE && p0 && !c0clear) {
+                    float te;
+                    p0 = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cdx, cdy, cdz, te);
+                }
+                if(k1 == REF_INSTANCE && p1 && !c1clear) {
+                    float te;
+                    p1 = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cdx, cdy, cdz, te);
+                }
+                p0 = p0 && t0 <= prune_t;
+                p1 = p1 && t1 <= prune_t;
+                if(p0 && p1) {
+                    // nearer child next, farther one deferred
+                    const bool swap = t1 < t0;
+                    const unsigned rn = swap ? c1 : c0, rf = swap ? c0 : c1;
+                    const float tnn = swap ? t1 : t0, tf = swap ? t0 : t1;
+                    const uint2 e = make_uint2(rf, __float_as_uint(tf));
+                    if(sp < FAST_LDS_STACK) {
+                        s_stack[sp * FAST_BLOCK + tid] = e;
+                        ++sp;
+                    } else if(sp - FAST_LDS_STACK < sc.spill_depth) {
+                        sc.spill[(size_t)(sp - FAST_LDS_STACK) * nthreads + gtid] = e;
+                        ++sp;
+                    } else {
+                        *sc.error_flag = 1u;
+                    }
+                    ref = rn;
+                    tn = tnn;
+                } else if(p0) {
+                    ref = c0;
+                    tn = t0;
+                } else if(p1) {
+                    ref = c1;
+                    tn = t1;
+                } else {
+                    have = false;
+                }
+            } else if(have && kind == REF_INSTANCE) {
+                // entry into the instance: rows of world-to-local, then the mesh root
+                cox = (q0.x * wox + q0.y * woy) + (q0.z * woz + q0.w);
+                coy = (q1.x * wox + q1.y * woy) + (q1.z * woz + q1.w);
+                coz = (q2.x * wox + q2.y * woy) + (q2.z * woz + q2.w);
+                cdx = (q0.x * wdx + q0.y * wdy) + q0.z * wdz;
+                cdy = (q1.x * wdx + q1.y * wdy) + q1.z * wdz;
+                cdz = (q2.x * wdx + q2.y * wdy) + q2.z * wdz;
+                cix = 1.0f / cdx; ciy = 1.0f / cdy; ciz = 1.0f / cdz;
+                in_mesh = true;
+                cur_inst = (int)idx;
+                ref = __float_as_uint(q3.x);  // mesh root; its own box is implied by the boxes below it
+            } else if(have) {
+                // triangle leaf: q0, q1.xy parent box; then v0, e1, e2
+                const float v0x = q1.z, v0y = q1.w, v0z = q2.x;
+                const float e1x = q2.y, e1y = q2.z, e1z = q2.w;
+                const float e2x = q3.x, e2y = q3.y, e2z = q3.z;
+                // intersect_triangle, shader/pathtracing.glsl:224-249
+                const float sx = cox - v0x, sy = coy - v0y, sz = coz - v0z;
+                const float s1x = cdy * e2z - e2y * cdz, s1y = cdz * e2x - e2z * cdx, s1z = cdx * e2y - e2x * cdy;
+                const float s2x = sy * e1z - e1y * sz, s2y = sz * e1x - e1z * sx, s2z = sx * e1y - e1x * sy;
+                const float k = 1.0f / (s1x * e1x + s1y * e1y + s1z * e1z);
+                const float t = (s2x * e2x + s2y * e2y + s2z * e2z) * k;
+                const float u = (s1x * sx + s1y * sy + s1z * sz) * k;
+                const float v = (s2x * cdx + s2y * cdy + s2z * cdz) * k;
+                have = false;
+                if(RT_RAY_MINDIS <= t && 0.0f <= u && 0.0f <= v && u + v <= 1.0f) {
+                    if(t < best.t) {
+                        // candidate only if the reference would have reached this leaf
+                        bool clear;
+                        float t0;
+                        bool pass = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, clear);
+                        if(pass && !clear) {
+                            float te;
+                            pass = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cdx, cdy, cdz, te);
+                        }
+                        if(pass) {
+                            second_t = fminf(second_t, best.t);
+                            best.t = t; best.u = u; best.v = v;
+                            best.tri = (int)idx;
+                            best.inst = cur_inst;
+                            if(any_hit) sp = 0;
+                        }
+                    } else {
+                        second_t = fminf(second_t, t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace rta

@@ -1,41 +1,70 @@
-// The three users of the traversal core: stand-alone closest hit (pt_pass_intersect), the
-// path tracer's extend stage and its shadow stage.
+// Users of the two traversal cores: stand-alone closest hit (pt_pass_intersect), the path
+// tracer's extend stage and its shadow stage.  Each exists in a reference-order form
+// (trace_core.h, exact by construction) and an ordered form (trace_fast.h) that hands the
+// rays it cannot decide (near-ties in t) to the reference-order form through a redo queue.
 #include "kernels.h"
+#include "trace_fast.h"
 
 namespace rta {
 namespace {
 
 // ---- stand-alone closest hit -----------------------------------------------------------
+// `redo`, when given, lists the ray indices to trace (the ordered kernel's undecided rays).
 struct RaySource {
     const float *rays;
+    const unsigned *redo;
     __device__ bool load(unsigned idx, float o[3], float d[3], bool &any_hit) const {
-        const float2 *p = reinterpret_cast<const float2 *>(rays + (size_t)idx * 6);
-        const float2 a = p[0], b = p[1], c = p[2];
-        o[0] = a.x; o[1] = a.y; o[2] = b.x;
-        d[0] = b.y; d[1] = c.x; d[2] = c.y;
+        const unsigned r = redo ? redo[idx] : idx;
+        // streamed once: keep it from displacing the scene in the caches
+        const float *p = rays + (size_t)r * 6;
+        o[0] = __builtin_nontemporal_load(p + 0);
+        o[1] = __builtin_nontemporal_load(p + 1);
+        o[2] = __builtin_nontemporal_load(p + 2);
+        d[0] = __builtin_nontemporal_load(p + 3);
+        d[1] = __builtin_nontemporal_load(p + 4);
+        d[2] = __builtin_nontemporal_load(p + 5);
         any_hit = false;
         return true;
     }
 };
+__device__ __forceinline__ void write_hit(pt_hit *hits, unsigned r, const LaneHit &h) {
+    pt_hit *x = hits + r;
+    __builtin_nontemporal_store(h.inst, &x->instance);
+    __builtin_nontemporal_store(h.tri, &x->triangle);
+    __builtin_nontemporal_store(h.t, &x->t);
+    __builtin_nontemporal_store(h.u, &x->u);
+    __builtin_nontemporal_store(h.v, &x->v);
+}
 struct HitSink {
     pt_hit *hits;
-    __device__ void store(unsigned idx, const LaneHit &h) const {
-        pt_hit r;
-        r.instance = h.inst;
-        r.triangle = h.tri;
-        r.t = h.t;
-        r.u = h.u;
-        r.v = h.v;
-        hits[idx] = r;
+    const unsigned *redo;
+    __device__ void store(unsigned idx, const LaneHit &h) const { write_hit(hits, redo ? redo[idx] : idx, h); }
+};
+struct HitSinkFast {
+    pt_hit *hits;
+    unsigned *redo, *redo_count;
+    __device__ void store(unsigned idx, const LaneHit &h, bool ambiguous) const {
+        if(ambiguous) redo[atomicAdd(redo_count, 1u)] = idx;
+        else write_hit(hits, idx, h);
     }
 };
 
 __global__ __launch_bounds__(TRACE_BLOCK) void intersect_kernel(TraceScene sc, const float *rays, unsigned n,
+                                                                const unsigned *redo, const unsigned *redo_count,
                                                                 pt_hit *hits, unsigned *next_counter) {
     __shared__ uint2 s_stack[LDS_STACK * TRACE_BLOCK];
-    RaySource src{rays};
-    HitSink sink{hits};
-    trace_persistent(sc, src, sink, next_counter, n, s_stack);
+    RaySource src{rays, redo};
+    HitSink sink{hits, redo};
+    trace_persistent(sc, src, sink, next_counter, redo ? *redo_count : n, s_stack);
+}
+
+__global__ __launch_bounds__(FAST_BLOCK) void intersect_fast_kernel(FastScene sc, const float *rays, unsigned n,
+                                                                    pt_hit *hits, unsigned *next_counter,
+                                                                    unsigned *redo, unsigned *redo_count) {
+    __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
+    RaySource src{rays, nullptr};
+    HitSinkFast sink{hits, redo, redo_count};
+    trace_ordered(sc, src, sink, next_counter, n, s_stack);
 }
 
 // ---- extend ------------------------------------------------------------------------------
@@ -52,14 +81,24 @@ struct ExtendSource {
         return true;
     }
 };
+__device__ __forceinline__ void write_path_hit(PathHit *hits, unsigned px, const LaneHit &h) {
+    float4 *p = reinterpret_cast<float4 *>(hits + px);
+    p[0] = make_float4(h.t, h.u, h.v, __int_as_float(h.tri));
+    p[1] = make_float4(__int_as_float(h.inst), 0.0f, 0.0f, 0.0f);
+}
 struct ExtendSink {
     const unsigned *queue;
     PathHit *hits;
-    __device__ void store(unsigned idx, const LaneHit &h) const {
+    __device__ void store(unsigned idx, const LaneHit &h) const { write_path_hit(hits, queue ? queue[idx] : idx, h); }
+};
+struct ExtendSinkFast {
+    const unsigned *queue;
+    PathHit *hits;
+    unsigned *redo, *redo_count;  // redo lists PIXEL slots, so the reference-order extend can take it as its queue
+    __device__ void store(unsigned idx, const LaneHit &h, bool ambiguous) const {
         const unsigned px = queue ? queue[idx] : idx;
-        float4 *p = reinterpret_cast<float4 *>(hits + px);
-        p[0] = make_float4(h.t, h.u, h.v, __int_as_float(h.tri));
-        p[1] = make_float4(__int_as_float(h.inst), 0.0f, 0.0f, 0.0f);
+        if(ambiguous) redo[atomicAdd(redo_count, 1u)] = px;
+        else write_path_hit(hits, px, h);
     }
 };
 
@@ -70,6 +109,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void extend_kernel(TraceScene sc, cons
     ExtendSource src{queue, rays};
     ExtendSink sink{queue, hits};
     trace_persistent(sc, src, sink, next_counter, *count, s_stack);
+}
+
+__global__ __launch_bounds__(FAST_BLOCK) void extend_fast_kernel(FastScene sc, const unsigned *queue,
+                                                                 const unsigned *count, const PathRay *rays,
+                                                                 PathHit *hits, unsigned *next_counter,
+                                                                 unsigned *redo, unsigned *redo_count) {
+    __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
+    ExtendSource src{queue, rays};
+    ExtendSinkFast sink{queue, hits, redo, redo_count};
+    trace_ordered(sc, src, sink, next_counter, *count, s_stack);
 }
 
 // ---- shadow ------------------------------------------------------------------------------
@@ -106,6 +155,8 @@ struct ShadowSink {
         const bool visible = h.tri < 0 || h.t * h.t > e->dis2;
         if(visible) e->flags |= 4u;
     }
+    // occlusion queries are never ambiguous
+    __device__ void store(unsigned idx, const LaneHit &h, bool) const { store(idx, h); }
 };
 
 __global__ __launch_bounds__(TRACE_BLOCK) void shadow_kernel(TraceScene sc, const unsigned *queue,
@@ -118,11 +169,29 @@ __global__ __launch_bounds__(TRACE_BLOCK) void shadow_kernel(TraceScene sc, cons
     trace_persistent(sc, src, sink, next_counter, *count * (unsigned)n_shadow, s_stack);
 }
 
+// sky-only form (n_shadow == 1): every query is an occlusion query
+__global__ __launch_bounds__(FAST_BLOCK) void shadow_fast_kernel(FastScene sc, const unsigned *queue,
+                                                                 const unsigned *count, const PathRay *rays,
+                                                                 ShadowEntry *shadow, int npix,
+                                                                 unsigned *next_counter) {
+    __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
+    ShadowSource src{queue, rays, shadow, 1, npix};
+    ShadowSink sink{queue, shadow, 1, npix};
+    trace_ordered(sc, src, sink, next_counter, *count, s_stack);
+}
+
 }  // namespace
 
-void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n, pt_hit *hits,
-                      unsigned *next_counter) {
-    hipLaunchKernelGGL(intersect_kernel, dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, rays, n, hits, next_counter);
+void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n,
+                      const unsigned *redo, const unsigned *redo_count, pt_hit *hits, unsigned *next_counter) {
+    hipLaunchKernelGGL(intersect_kernel, dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, rays, n, redo, redo_count, hits,
+                       next_counter);
+}
+
+void launch_intersect_fast(hipStream_t s, const FastScene &sc, int blocks, const float *rays, unsigned n,
+                           pt_hit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count) {
+    hipLaunchKernelGGL(intersect_fast_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, rays, n, hits, next_counter,
+                       redo, redo_count);
 }
 
 void launch_extend(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
@@ -131,10 +200,23 @@ void launch_extend(hipStream_t s, const TraceScene &sc, int blocks, const unsign
                        next_counter);
 }
 
+void launch_extend_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                        const PathRay *rays, PathHit *hits, unsigned *next_counter, unsigned *redo,
+                        unsigned *redo_count) {
+    hipLaunchKernelGGL(extend_fast_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, hits,
+                       next_counter, redo, redo_count);
+}
+
 void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                    const PathRay *rays, ShadowEntry *shadow, int n_shadow, int npix, unsigned *next_counter) {
     hipLaunchKernelGGL(shadow_kernel, dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, queue, count, rays, shadow,
                        n_shadow, npix, next_counter);
+}
+
+void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                        const PathRay *rays, ShadowEntry *shadow, int npix, unsigned *next_counter) {
+    hipLaunchKernelGGL(shadow_fast_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, shadow, npix,
+                       next_counter);
 }
 
 }  // namespace rta

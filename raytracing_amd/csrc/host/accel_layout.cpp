@@ -1,6 +1,8 @@
 #include "accel_layout.h"
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <limits>
 
 namespace rta {
 namespace {
@@ -80,6 +82,36 @@ bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo
             t.pad[k] = 0.0f;
         }
     }
+    // ---- ordered-traversal leaves: triangle + exact box of the reference parent node
+    out.tri_leaf.resize(n_tris);
+    {
+        const float inf = std::numeric_limits<float>::infinity();
+        for(size_t i = 0; i < n_tris; i++) {
+            TLeaf &l = out.tri_leaf[i];
+            const TriPos &t = out.tri_pos[i];
+            for(int k = 0; k < 3; k++) {
+                l.parent_lo[k] = -inf;
+                l.parent_hi[k] = inf;
+                l.v0[k] = t.v0[k];
+                l.e1[k] = t.e1[k];
+                l.e2[k] = t.e2[k];
+            }
+            l.pad = 0.0f;
+        }
+        for(size_t ii = 0; ii < n_mesh_nodes; ii++) {
+            const BVHNodeInfo &p = mesh[ii];
+            if(p.triangleIndex >= 0) continue;
+            const int32_t kids[2] = {p.lsIndex, p.rsIndex};
+            for(int32_t c : kids)
+                if(mesh[c].triangleIndex >= 0) {
+                    TLeaf &l = out.tri_leaf[mesh[c].triangleIndex];
+                    for(int k = 0; k < 3; k++) {
+                        l.parent_lo[k] = p.aa[k];
+                        l.parent_hi[k] = p.bb[k];
+                    }
+                }
+        }
+    }
     // ---- instances
     out.instances.resize(n_inst);
     int max_mesh_height = 1;
@@ -100,7 +132,12 @@ bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo
         set_box(a.root_lo, a.root_hi, root);
         a.root_ref = mesh_ref(s.meshIndex);
         a.material_ptr = s.materialPtr;
-        memset(a.pad, 0, sizeof a.pad);
+        for(int k = 0; k < 3; k++) {
+            a.world_lo[k] = 0.0f;
+            a.world_hi[k] = 0.0f;
+        }
+        memset(a.pad0, 0, sizeof a.pad0);
+        memset(a.pad1, 0, sizeof a.pad1);
         max_mesh_height = std::max(max_mesh_height, height[s.meshIndex]);
     }
     // ---- scene level
@@ -134,7 +171,14 @@ bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo
         t.c1 = scene_ref(p.rsIndex);
         sheight[ii] = std::max(sheight[p.lsIndex], sheight[p.rsIndex]) + 1;
     }
+    for(size_t i = 0; i < n_scene_nodes; i++)
+        if(scene[i].instanceIndex >= 0) {
+            InstAccel &a = out.instances[scene[i].instanceIndex];
+            set_box(a.world_lo, a.world_hi, scene[i]);
+        }
     set_box(out.header.root_lo, out.header.root_hi, scene[0]);
+    out.header.extent = 0.0f;
+    for(int k = 0; k < 3; k++) out.header.extent += std::fabs(scene[0].aa[k]) > std::fabs(scene[0].bb[k]) ? std::fabs(scene[0].aa[k]) : std::fabs(scene[0].bb[k]);
     out.header.root_ref = scene_ref(0);
     out.header.n_instances = (uint32_t)n_inst;
     // each level of a walk defers at most one sibling

@@ -14,6 +14,7 @@ struct AccelHost {
     std::vector<TNode> mesh_nodes;
     std::vector<TNode> scene_nodes;
     std::vector<TriPos> tri_pos;
+    std::vector<TLeaf> tri_leaf;   // same index as tri_pos
     std::vector<InstAccel> instances;
     SceneHeader header;
     int max_stack = 0;  // upper bound of deferred entries one ray can hold (scene + mesh height)

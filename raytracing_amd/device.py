@@ -197,6 +197,10 @@ class PathTracingPass:
         return dict(samples=int(s.samples), rays_extend=int(s.rays_extend), rays_shadow=int(s.rays_shadow),
                     draws=int(s.draws))
 
+    def set_traversal(self, mode):
+        """0 = ordered traversal with exact fallback (default), 1 = reference order only."""
+        check(lib.pt_pass_set_traversal(self.h, int(mode)))
+
     def set_profiling(self, enable=True):
         check(lib.pt_pass_set_profiling(self.h, int(enable)))
 

@@ -32,3 +32,53 @@ def test_casa_random_rays(casa, oracle_mod, gpu_ctx):
     _check(hits, ref)
     p.destroy()
     sb.release()
+
+
+def test_reference_order_mode_matches_too(casa, oracle_mod, gpu_ctx):
+    """pt_pass_set_traversal(1): every ray in the reference's visiting order."""
+    from raytracing_amd import device
+    lo, hi = casa.world_box()
+    rays = random_rays(lo, hi, 1 << 18, 11)
+    sb = device.SceneBuffers(gpu_ctx, casa)
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    p.bind_scene(sb)
+    p.set_traversal(1)
+    hits = device.trace_rays(p, rays)
+    ref, _ = oracle_mod.OracleScene(casa).intersect(rays)
+    _check(hits, ref)
+    p.destroy()
+    sb.release()
+
+
+def test_degenerate_rays(casa, oracle_mod, gpu_ctx):
+    """Axis-parallel directions (zero components: infinities and NaNs in the slab test),
+    origins on box planes, rays starting on surfaces, unnormalised and tiny directions."""
+    from raytracing_amd import device
+    lo, hi = casa.world_box()
+    rng = np.random.default_rng(5)
+    n = 20000
+    o = lo + (hi - lo) * rng.random((n, 3))
+    d = np.zeros((n, 3))
+    ax = rng.integers(0, 3, n)
+    d[np.arange(n), ax] = rng.choice([-1.0, 1.0], n)
+    two = rng.random(n) < 0.3                      # a second non-zero component on some
+    d[two, (ax[two] + 1) % 3] = rng.standard_normal(two.sum())
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    rays[:200, :3] = lo                            # origins exactly on the scene box corner
+    rays[200:400, 3:] *= 1e-3                      # short direction vectors: t scales up
+    rays[400:600, 3:] *= 250.0
+    sb = device.SceneBuffers(gpu_ctx, casa)
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    p.bind_scene(sb)
+    osc = oracle_mod.OracleScene(casa)
+    ref, _ = osc.intersect(rays)
+    _check(device.trace_rays(p, rays), ref)
+    # second generation: start exactly on the surfaces just hit, bounce along the normal-ish axis
+    h = ref["triangle"] >= 0
+    pos = rays[h, :3] + ref["t"][h, None] * rays[h, 3:]
+    d2 = rng.standard_normal((h.sum(), 3))
+    rays2 = np.concatenate([pos, d2], 1).astype(np.float32)
+    ref2, _ = osc.intersect(rays2)
+    _check(device.trace_rays(p, rays2), ref2)
+    p.destroy()
+    sb.release()
