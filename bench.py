@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tris", type=int, default=10_000_000, help="synth_pt: triangle count")
     ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
+    ap.add_argument("--pipeline", type=int, default=3, help="draws in flight on the device (pt_pass_set_pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel events (no roofline)")
     return ap.parse_args()
@@ -141,11 +142,9 @@ def main():
         if world > 1:
             for name in multigpu.ACCUMULATED:   # sums start from zero on every rank
                 p.outputs[name].fill(0.0)
+        p.set_pipeline(args.pipeline)
         barrier()
         p.stats(reset=True)
-        if not args.no_profile:
-            p.set_profiling(True)
-            p.profile(reset=True)
         t0 = time.perf_counter()
         for s in my_samples:
             draw(s, accum_mode)
@@ -154,11 +153,29 @@ def main():
             multigpu.allreduce_outputs(torch, dist, p, npix, total_spp, dev_tensor)
         barrier()
         dt = time.perf_counter() - t0
-        st = p.stats()
+        st = p.stats(reset=True)
         units_per_rank = dict(rays=st["rays_extend"] + st["rays_shadow"], samples=st["samples"],
                               rays_extend=st["rays_extend"], rays_shadow=st["rays_shadow"])
-        prof = p.profile() if not args.no_profile else None
-        dominant = ("extend_kernel", prof["extend_ms"], prof["extend_launches"], st["rays_extend"]) if prof else None
+        # Per-kernel times: the same draws once more, one at a time (overlapping draws would
+        # be charged each other's time), bracketed by HIP events on the launching stream.
+        prof = dominant = None
+        if not args.no_profile:
+            p.set_pipeline(1)
+            p.set_profiling(True)
+            p.profile(reset=True)
+            n_prof = min(len(my_samples), 16)
+            t1 = time.perf_counter()
+            for s in list(my_samples)[:n_prof]:
+                draw(s, accum_mode)
+            ctx.synchronize()
+            serial_ms = (time.perf_counter() - t1) / n_prof * 1e3
+            prof = p.profile()
+            pst = p.stats(reset=True)
+            p.set_profiling(False)
+            p.set_pipeline(args.pipeline)
+            prof["draws"] = n_prof
+            prof["serial_ms_per_step"] = serial_ms
+            dominant = ("extend_fast_kernel + extend_kernel", prof["extend_ms"], prof["extend_launches"], pst["rays_extend"])
 
     # max time over ranks, sum of units over ranks
     if world > 1:
@@ -191,6 +208,7 @@ def main():
                                     "synth_pt": "synthetic %d-triangle scene %dx%d path trace, 1 spp per step, max depth %d" % (len(sd.triangles), W, H, args.depth)}[wl],
                        "resolution": [W, H] if wl != "casa_isect" else None,
                        "triangles": int(len(sd.triangles)), "instances": int(len(sd.instances)),
+                       "draws_in_flight": args.pipeline if wl != "casa_isect" else None,
                        "parallelism": "sample slicing x%d, one all-reduce" % world if world > 1 else "single GPU"},
             "msamples_per_s": total_samples / dt / 1e6,
             "rays_per_sample": (total_rays / total_samples) if total_samples else None,
@@ -252,6 +270,12 @@ def main():
                                    "rays_per_launch": rays_in_kernel / launches}
             if prof:
                 out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms")}
+                if "draws" in prof:
+                    out["kernel_ms"]["over_draws"] = prof["draws"]
+                    out["kernel_ms"]["one_draw_in_flight_ms_per_step"] = prof["serial_ms_per_step"]
+                    if b_ray is not None:
+                        # what the whole pipelined frame sustains, extend rays only
+                        out["roofline"]["measured_on"] = "%d draws issued one at a time after the timed region" % prof["draws"]
         print(json.dumps(out), flush=True)
 
     p.destroy()

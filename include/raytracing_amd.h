@@ -164,7 +164,18 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
  *   1 the reference's visiting order for every ray (shader/pathtracing.glsl:254-316). */
 int pt_pass_set_traversal(pt_pass *pass, int mode);
 
-/* Per-kernel device time, measured with HIP events recorded on the context's stream around
+/* How many draws may be in flight on the device at once (1..8, default 3); no counterpart in
+ * the reference, whose GL driver queues frames by itself.  pt_pass_draw returns as soon as
+ * the draw is queued; consecutive draws run on separate HIP streams with path state of their
+ * own, so the thin late bounces of one overlap the wide early bounces of the next.  The
+ * outputs are the same as with 1: the last-write outputs and the running mean are applied in
+ * call order.  Every other call on the context (uploads, downloads, pt_ctx_synchronize,
+ * pt_pass_stats ...) waits for the draws issued before it.  Each draw in flight holds about
+ * 210 bytes per pixel of path state.  While profiling is enabled (pt_pass_set_profiling) the
+ * per-kernel times of overlapping draws include each other: profile with 1. */
+int pt_pass_set_pipeline(pt_pass *pass, int draws_in_flight);
+
+/* Per-kernel device time, measured with HIP events recorded on the launching stream around
  * every launch while profiling is enabled.  No counterpart in the reference (its only
  * timing is an FPS counter, main.cpp:423-435); used by bench.py for the roofline figure. */
 typedef struct pt_profile {

@@ -85,6 +85,7 @@ SIGNATURES = {
     "pt_pass_output": (C.c_int, [C.c_void_p, C.c_int, c_void_pp]),
     "pt_pass_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats), C.c_int]),
     "pt_pass_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_pass_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_profile": (C.c_int, [C.c_void_p, C.POINTER(PtProfile), C.c_int]),
     "pt_pass_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

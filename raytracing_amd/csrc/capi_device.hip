@@ -25,7 +25,25 @@ struct pt_ctx {
     int num_cus = 0;
     uint64_t next_handle = 1;
     std::unordered_map<uint64_t, pt_tex *> textures;
+    // Draws run on streams of their own (pt_pass::lanes).  Each leaves its completion event
+    // here; everything issued on `stream` first makes `stream` wait for them (ctx_join).
+    std::vector<hipEvent_t> pending;
 };
+
+// Orders the context's main stream behind every draw issued so far.
+static int ctx_join(pt_ctx *ctx) {
+    for(hipEvent_t e : ctx->pending) {
+        hipError_t r = hipStreamWaitEvent(ctx->stream, e, 0);
+        if(r != hipSuccess) return fail(PT_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(r));
+    }
+    ctx->pending.clear();
+    return PT_OK;
+}
+#define JOIN_TRY(ctx)                       \
+    do {                                    \
+        int _rc = ctx_join(ctx);            \
+        if(_rc) return _rc;                 \
+    } while(0)
 
 struct pt_buf {
     pt_ctx *ctx = nullptr;
@@ -94,14 +112,30 @@ struct pt_pass {
     bool accel_valid = false;
     AccelHost accel_info;  // header + sizes (vectors are cleared after upload)
     DeviceArray d_mesh_nodes, d_scene_nodes, d_tri_pos, d_tri_leaf, d_inst, d_spill, d_tex_table;
-    DeviceArray d_queue_r, d_redo_isect;  // redo lists of the ordered extend / intersect
+    DeviceArray d_redo_isect;  // redo list of the ordered intersect
     int traversal_mode = 0;               // 0 ordered + exact fallback, 1 reference order only
     int n_textures = 0;
     int spill_depth = 0;
     size_t n_material_floats = 0;
-    // path state
-    DeviceArray d_rays, d_hits, d_thr, d_acc, d_shadow, d_queue_a, d_queue_b, d_queue_s, d_counters, d_stats, d_err;
-    int shadow_capacity = 0;
+    // Path state.  Consecutive draws are independent until they touch the outputs, so each
+    // draw runs on one of `n_lanes` streams with path state of its own: the narrow late
+    // bounces of one draw overlap the wide early bounces of the next.  Events keep the two
+    // places where draws do meet in call order: the last-write outputs written while shading
+    // the first vertex, and the running mean in finalize.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        DeviceArray rays, hits, thr, acc, shadow, queue_a, queue_b, queue_s, queue_r, counters, spill;
+        int shadow_capacity = 0;
+        int spill_depth = 0;
+        hipEvent_t done = nullptr, gbuf = nullptr, fin = nullptr, start = nullptr;
+    };
+    static constexpr int MAX_LANES = 8;
+    Lane lanes[MAX_LANES];
+    int n_lanes = 3;
+    int next_lane = 0;
+    hipEvent_t last_gbuf = nullptr, last_fin = nullptr;  // of the previous draw; null before the first
+    hipStream_t cur_stream = nullptr;                    // stream the ScopedTimer records on
+    DeviceArray d_counters, d_stats, d_err;
     int trace_blocks = 0;
     int redo_blocks = 0;  // grid of the (small) reference-order launches behind the ordered ones
     // optional per-kernel timing
@@ -121,6 +155,7 @@ int download_shadow(pt_buf *b, std::vector<uint8_t> &out) {
     }
     out.resize(b->bytes);
     if(b->bytes) {
+        JOIN_TRY(b->ctx);
         HIP_TRY(hipStreamSynchronize(b->ctx->stream));
         HIP_TRY(hipMemcpy(out.data(), b->dptr, b->bytes, hipMemcpyDeviceToHost));
     }
@@ -128,6 +163,9 @@ int download_shadow(pt_buf *b, std::vector<uint8_t> &out) {
 }
 
 int upload_array(pt_ctx *ctx, DeviceArray &d, const void *src, size_t bytes) {
+    // the array may still be read by draws in flight
+    JOIN_TRY(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     int rc = d.ensure(bytes);
     if(rc) return rc;
     if(bytes) {
@@ -195,6 +233,8 @@ int prepare_scene(pt_pass *p) {
             int need = ah.max_stack + 2 - (LDS_STACK < FAST_LDS_STACK ? LDS_STACK : FAST_LDS_STACK);
             if(need < 0) need = 0;
             if(need > p->spill_depth || !p->d_spill.p) {
+                JOIN_TRY(ctx);
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
                 p->spill_depth = need < 4 ? 4 : need;
                 const size_t nthreads = (size_t)p->trace_blocks * TRACE_BLOCK;
                 if((rc = p->d_spill.ensure(nthreads * (size_t)p->spill_depth * sizeof(uint2)))) return rc;
@@ -237,14 +277,15 @@ int prepare_scene(pt_pass *p) {
     return PT_OK;
 }
 
-TraceScene make_trace_scene(pt_pass *p) {
+// spill == nullptr: the pass's own spill area (launches on the main stream)
+TraceScene make_trace_scene(pt_pass *p, void *spill = nullptr) {
     TraceScene sc;
     sc.mesh_nodes = static_cast<const TNode *>(p->d_mesh_nodes.p);
     sc.scene_nodes = static_cast<const TNode *>(p->d_scene_nodes.p);
     sc.tri_pos = static_cast<const TriPos *>(p->d_tri_pos.p);
     sc.inst = static_cast<const InstAccel *>(p->d_inst.p);
     sc.hdr = p->accel_info.header;
-    sc.spill = static_cast<uint2 *>(p->d_spill.p);
+    sc.spill = static_cast<uint2 *>(spill ? spill : p->d_spill.p);
     sc.spill_depth = p->spill_depth;
     sc.error_flag = static_cast<unsigned *>(p->d_err.p);
     return sc;
@@ -271,11 +312,11 @@ struct ScopedTimer {
         if(!p->profiling) return;
         a = take(p);
         b = take(p);
-        if(a) (void)hipEventRecord(a, p->ctx->stream);
+        if(a) (void)hipEventRecord(a, p->cur_stream);
     }
     ~ScopedTimer() {
         if(!p->profiling || !a || !b) return;
-        (void)hipEventRecord(b, p->ctx->stream);
+        (void)hipEventRecord(b, p->cur_stream);
         p->timed.push_back({kind, a, b});
     }
 };
@@ -299,14 +340,14 @@ void collect_profile(pt_pass *p) {
     p->timed.clear();
 }
 
-FastScene make_fast_scene(pt_pass *p) {
+FastScene make_fast_scene(pt_pass *p, void *spill = nullptr) {
     FastScene sc;
     sc.mesh_nodes = static_cast<const TNode *>(p->d_mesh_nodes.p);
     sc.scene_nodes = static_cast<const TNode *>(p->d_scene_nodes.p);
     sc.tri_leaf = static_cast<const TLeaf *>(p->d_tri_leaf.p);
     sc.inst = static_cast<const InstAccel *>(p->d_inst.p);
     sc.hdr = p->accel_info.header;
-    sc.spill = static_cast<uint2 *>(p->d_spill.p);
+    sc.spill = static_cast<uint2 *>(spill ? spill : p->d_spill.p);
     sc.spill_depth = p->spill_depth;
     sc.error_flag = static_cast<unsigned *>(p->d_err.p);
     return sc;
@@ -317,6 +358,55 @@ TexDesc desc_of(const pt_tex *t) {
     d.data = t->dptr;
     d.width = t->width; d.height = t->height; d.channels = t->channels; d.format = t->format;
     return d;
+}
+
+void release_lane(pt_pass::Lane &l) {
+    if(l.stream) {
+        (void)hipStreamSynchronize(l.stream);
+        (void)hipStreamDestroy(l.stream);
+    }
+    for(hipEvent_t *e : {&l.done, &l.gbuf, &l.fin, &l.start})
+        if(*e) {
+            (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
+    DeviceArray *arrs[] = {&l.rays, &l.hits, &l.thr, &l.acc, &l.shadow, &l.queue_a, &l.queue_b, &l.queue_s, &l.queue_r, &l.counters, &l.spill};
+    for(DeviceArray *a : arrs) a->release();
+    l = pt_pass::Lane();
+}
+
+// Stream, events and path state of one lane, sized for the pass and the scene bound now.
+int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow) {
+    const size_t npix = (size_t)p->W * p->H;
+    if(!l.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        for(hipEvent_t *e : {&l.done, &l.gbuf, &l.fin, &l.start}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        int rc = PT_OK;
+        if(!rc) rc = l.rays.ensure(npix * sizeof(PathRay));
+        if(!rc) rc = l.hits.ensure(npix * sizeof(PathHit));
+        if(!rc) rc = l.thr.ensure(npix * sizeof(PathThroughput));
+        if(!rc) rc = l.acc.ensure(npix * sizeof(PathAccum));
+        if(!rc) rc = l.queue_a.ensure(npix * 4);
+        if(!rc) rc = l.queue_b.ensure(npix * 4);
+        if(!rc) rc = l.queue_s.ensure(npix * 4);
+        if(!rc) rc = l.queue_r.ensure(npix * 4);
+        if(!rc) rc = l.counters.ensure(CNT_TOTAL * 4);
+        if(rc) return rc;
+    }
+    if(n_shadow > l.shadow_capacity) {
+        HIP_TRY(hipStreamSynchronize(l.stream));
+        int rc = l.shadow.ensure(npix * n_shadow * sizeof(ShadowEntry));
+        if(rc) return rc;
+        l.shadow_capacity = n_shadow;
+    }
+    if(l.spill_depth < p->spill_depth || !l.spill.p) {
+        HIP_TRY(hipStreamSynchronize(l.stream));
+        const size_t nthreads = (size_t)p->trace_blocks * TRACE_BLOCK;
+        int rc = l.spill.ensure(nthreads * (size_t)p->spill_depth * sizeof(uint2));
+        if(rc) return rc;
+        l.spill_depth = p->spill_depth;
+    }
+    return PT_OK;
 }
 
 }  // namespace
@@ -349,6 +439,7 @@ int pt_ctx_create(int device_id, pt_ctx **out) {
 int pt_ctx_destroy(pt_ctx *ctx) {
     if(!ctx) return PT_OK;
     (void)hipSetDevice(ctx->device);
+    (void)ctx_join(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -357,6 +448,8 @@ int pt_ctx_destroy(pt_ctx *ctx) {
 
 int pt_ctx_synchronize(pt_ctx *ctx) {
     if(!ctx) return fail(PT_ERR_INVALID, "pt_ctx_synchronize: null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    JOIN_TRY(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
@@ -391,6 +484,7 @@ int pt_buf_create(pt_ctx *ctx, size_t bytes, const void *host, pt_buf **out) {
 int pt_buf_release(pt_buf *buf) {
     if(!buf) return PT_OK;
     (void)hipSetDevice(buf->ctx->device);
+    (void)ctx_join(buf->ctx);
     (void)hipStreamSynchronize(buf->ctx->stream);
     if(buf->dptr) (void)hipFree(buf->dptr);
     delete buf;
@@ -405,6 +499,7 @@ int pt_buf_upload(pt_buf *buf, const void *host, size_t bytes) {
     if(!bytes) return PT_OK;
     buf->shadow.assign(static_cast<const uint8_t *>(host), static_cast<const uint8_t *>(host) + bytes);
     buf->shadow_valid = true;
+    JOIN_TRY(buf->ctx);
     HIP_TRY(hipMemcpyAsync(buf->dptr, buf->shadow.data(), bytes, hipMemcpyHostToDevice, buf->ctx->stream));
     HIP_TRY(hipStreamSynchronize(buf->ctx->stream));
     return PT_OK;
@@ -418,6 +513,7 @@ int pt_buf_copy(pt_buf *dst, const pt_buf *src) {
     dst->version++;
     dst->shadow_valid = src->shadow_valid;
     if(src->shadow_valid) dst->shadow = src->shadow;
+    JOIN_TRY(dst->ctx);
     if(dst->bytes) HIP_TRY(hipMemcpyAsync(dst->dptr, src->dptr, dst->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
     return PT_OK;
 }
@@ -430,6 +526,7 @@ int pt_buf_fill(pt_buf *buf, const void *elem, size_t elem_bytes) {
     buf->shadow_valid = false;
     buf->shadow.clear();
     if(!buf->bytes) return PT_OK;
+    JOIN_TRY(buf->ctx);
     if(elem_bytes == 4) {
         uint32_t v;
         memcpy(&v, elem, 4);
@@ -452,6 +549,7 @@ int pt_buf_download(const pt_buf *buf, void *host, size_t bytes) {
     if(!buf || (!host && bytes)) return fail(PT_ERR_INVALID, "pt_buf_download: null argument");
     if(bytes > buf->bytes) return fail(PT_ERR_INVALID, "pt_buf_download: more bytes requested than the buffer holds");
     HIP_TRY(hipSetDevice(buf->ctx->device));
+    JOIN_TRY(buf->ctx);
     HIP_TRY(hipStreamSynchronize(buf->ctx->stream));
     if(bytes) HIP_TRY(hipMemcpy(host, buf->dptr, bytes, hipMemcpyDeviceToHost));
     return PT_OK;
@@ -488,6 +586,7 @@ int pt_tex_create(pt_ctx *ctx, int width, int height, int channels, int format, 
 int pt_tex_release(pt_tex *tex) {
     if(!tex) return PT_OK;
     (void)hipSetDevice(tex->ctx->device);
+    (void)ctx_join(tex->ctx);
     (void)hipStreamSynchronize(tex->ctx->stream);
     tex->ctx->textures.erase(tex->handle);
     if(tex->dptr) (void)hipFree(tex->dptr);
@@ -515,14 +614,6 @@ int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
     // 6 blocks of 256 threads per CU: 24 KiB of LDS stack each, 24 waves per CU
     p->trace_blocks = ctx->num_cus * 8;
     p->redo_blocks = ctx->num_cus;
-    if(!rc) rc = p->d_rays.ensure(npix * sizeof(PathRay));
-    if(!rc) rc = p->d_hits.ensure(npix * sizeof(PathHit));
-    if(!rc) rc = p->d_thr.ensure(npix * sizeof(PathThroughput));
-    if(!rc) rc = p->d_acc.ensure(npix * sizeof(PathAccum));
-    if(!rc) rc = p->d_queue_a.ensure(npix * 4);
-    if(!rc) rc = p->d_queue_b.ensure(npix * 4);
-    if(!rc) rc = p->d_queue_s.ensure(npix * 4);
-    if(!rc) rc = p->d_queue_r.ensure(npix * 4);
     if(!rc) rc = p->d_counters.ensure(CNT_TOTAL * 4);
     if(!rc) rc = p->d_stats.ensure(8 * 8);
     if(!rc) rc = p->d_err.ensure(16);
@@ -543,13 +634,14 @@ int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
 int pt_pass_destroy(pt_pass *p) {
     if(!p) return PT_OK;
     (void)hipSetDevice(p->ctx->device);
+    (void)ctx_join(p->ctx);
     (void)hipStreamSynchronize(p->ctx->stream);
     for(int k = 0; k < 7; k++) pt_buf_release(p->outputs[k]);
     collect_profile(p);
     for(hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
-    DeviceArray *arrs[] = {&p->d_mesh_nodes, &p->d_scene_nodes, &p->d_tri_pos, &p->d_tri_leaf, &p->d_queue_r, &p->d_redo_isect, &p->d_inst, &p->d_spill, &p->d_tex_table,
-                           &p->d_rays, &p->d_hits, &p->d_thr, &p->d_acc, &p->d_shadow, &p->d_queue_a, &p->d_queue_b,
-                           &p->d_queue_s, &p->d_counters, &p->d_stats, &p->d_err};
+    for(pt_pass::Lane &l : p->lanes) release_lane(l);
+    DeviceArray *arrs[] = {&p->d_mesh_nodes, &p->d_scene_nodes, &p->d_tri_pos, &p->d_tri_leaf, &p->d_redo_isect, &p->d_inst,
+                           &p->d_spill, &p->d_tex_table, &p->d_counters, &p->d_stats, &p->d_err};
     for(DeviceArray *a : arrs) a->release();
     delete p;
     return PT_OK;
@@ -608,10 +700,9 @@ int pt_pass_draw(pt_pass *p) {
     }
     const size_t npix = (size_t)p->W * p->H;
     const int n_shadow = 1 + P.lightCount;
-    if(n_shadow > p->shadow_capacity) {
-        if((rc = p->d_shadow.ensure(npix * n_shadow * sizeof(ShadowEntry)))) return rc;
-        p->shadow_capacity = n_shadow;
-    }
+    pt_pass::Lane &L = p->lanes[p->next_lane];
+    p->next_lane = (p->next_lane + 1) % p->n_lanes;
+    if((rc = prepare_lane(p, L, n_shadow))) return rc;
 
     DrawParams dp;
     memset(&dp, 0, sizeof dp);
@@ -628,11 +719,11 @@ int pt_pass_draw(pt_pass *p) {
     dp.n_textures = p->n_textures;
     dp.sky = desc_of(p->sky);
     dp.sky_cache = p->sky_cache ? desc_of(p->sky_cache) : desc_of(p->sky);
-    dp.rays = static_cast<PathRay *>(p->d_rays.p);
-    dp.hits = static_cast<PathHit *>(p->d_hits.p);
-    dp.thr = static_cast<PathThroughput *>(p->d_thr.p);
-    dp.acc = static_cast<PathAccum *>(p->d_acc.p);
-    dp.shadow = static_cast<ShadowEntry *>(p->d_shadow.p);
+    dp.rays = static_cast<PathRay *>(L.rays.p);
+    dp.hits = static_cast<PathHit *>(L.hits.p);
+    dp.thr = static_cast<PathThroughput *>(L.thr.p);
+    dp.acc = static_cast<PathAccum *>(L.acc.p);
+    dp.shadow = static_cast<ShadowEntry *>(L.shadow.p);
     float *outs[7];
     for(int k = 0; k < 7; k++) {
         outs[k] = static_cast<float *>(p->outputs[k]->dptr);
@@ -642,21 +733,25 @@ int pt_pass_draw(pt_pass *p) {
     dp.o_albedo = outs[0]; dp.o_motion = outs[1]; dp.o_depth = outs[2]; dp.o_normal = outs[3];
     dp.o_inst = outs[4]; dp.o_direct = outs[5]; dp.o_indirect = outs[6];
     dp.stats = static_cast<unsigned long long *>(p->d_stats.p);
-    unsigned *cnt = static_cast<unsigned *>(p->d_counters.p);
+    unsigned *cnt = static_cast<unsigned *>(L.counters.p);
     dp.counters = cnt;
 
-    hipStream_t s = ctx->stream;
-    const TraceScene sc = make_trace_scene(p);
-    const FastScene fsc = make_fast_scene(p);
+    hipStream_t s = L.stream;
+    p->cur_stream = s;
+    // behind everything issued on the main stream so far (uploads, fills of the outputs)
+    HIP_TRY(hipEventRecord(L.start, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(s, L.start, 0));
+    const TraceScene sc = make_trace_scene(p, L.spill.p);
+    const FastScene fsc = make_fast_scene(p, L.spill.p);
     const bool ordered = p->traversal_mode == 0;
-    unsigned *qr = static_cast<unsigned *>(p->d_queue_r.p);
+    unsigned *qr = static_cast<unsigned *>(L.queue_r.p);
     HIP_TRY(hipMemsetAsync(cnt, 0, CNT_TOTAL * 4, s));
     {
         ScopedTimer t(p, K_OTHER);
         launch_generate(s, dp);
     }
-    unsigned *qa = static_cast<unsigned *>(p->d_queue_a.p), *qb = static_cast<unsigned *>(p->d_queue_b.p);
-    unsigned *qs = static_cast<unsigned *>(p->d_queue_s.p);
+    unsigned *qa = static_cast<unsigned *>(L.queue_a.p), *qb = static_cast<unsigned *>(L.queue_b.p);
+    unsigned *qs = static_cast<unsigned *>(L.queue_s.p);
     const unsigned *q_in = nullptr;  // vertex 0: every pixel, in pixel order
     for(int dep = 0; dep <= P.MAX_DEPTH; dep++) {
         unsigned *q_out = (dep & 1) ? qb : qa;
@@ -671,9 +766,15 @@ int pt_pass_draw(pt_pass *p) {
                 launch_extend(s, sc, p->trace_blocks, q_in, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
             }
         }
+        // shading the first vertex writes the last-write outputs: after the previous draw's
+        if(dep == 0 && p->last_gbuf && p->last_gbuf != L.gbuf) HIP_TRY(hipStreamWaitEvent(s, p->last_gbuf, 0));
         {
             ScopedTimer t(p, K_SHADE);
             launch_shade(s, dp, dep, q_in, cnt + CNT_QUEUE + dep, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep);
+        }
+        if(dep == 0) {
+            HIP_TRY(hipEventRecord(L.gbuf, s));
+            p->last_gbuf = L.gbuf;
         }
         if(dep < P.MAX_DEPTH) {
             {
@@ -690,11 +791,36 @@ int pt_pass_draw(pt_pass *p) {
         }
         q_in = q_out;
     }
+    // the running mean folds samples in call order
+    if(p->last_fin && p->last_fin != L.fin) HIP_TRY(hipStreamWaitEvent(s, p->last_fin, 0));
     {
         ScopedTimer t(p, K_OTHER);
         launch_finalize(s, dp);
     }
+    HIP_TRY(hipEventRecord(L.fin, s));
+    p->last_fin = L.fin;
+    HIP_TRY(hipEventRecord(L.done, s));
+    bool listed = false;
+    for(hipEvent_t e : ctx->pending) listed = listed || e == L.done;
+    if(!listed) ctx->pending.push_back(L.done);
     HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_pass_set_pipeline(pt_pass *pass, int draws_in_flight) {
+    if(!pass) return fail(PT_ERR_INVALID, "pt_pass_set_pipeline: null pass");
+    if(draws_in_flight < 1 || draws_in_flight > pt_pass::MAX_LANES)
+        return fail(PT_ERR_INVALID, "pt_pass_set_pipeline: draws in flight must be 1.." + std::to_string(pt_pass::MAX_LANES));
+    HIP_TRY(hipSetDevice(pass->ctx->device));
+    JOIN_TRY(pass->ctx);
+    HIP_TRY(hipStreamSynchronize(pass->ctx->stream));
+    for(int k = draws_in_flight; k < pt_pass::MAX_LANES; k++) {
+        if(pass->last_gbuf == pass->lanes[k].gbuf) pass->last_gbuf = nullptr;
+        if(pass->last_fin == pass->lanes[k].fin) pass->last_fin = nullptr;
+        release_lane(pass->lanes[k]);
+    }
+    pass->n_lanes = draws_in_flight;
+    pass->next_lane = 0;
     return PT_OK;
 }
 
@@ -711,6 +837,7 @@ int pt_pass_output(pt_pass *pass, int which, pt_buf **out) {
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     if(!pass || !out) return fail(PT_ERR_INVALID, "pt_pass_stats: null argument");
     HIP_TRY(hipSetDevice(pass->ctx->device));
+    JOIN_TRY(pass->ctx);
     HIP_TRY(hipStreamSynchronize(pass->ctx->stream));
     unsigned long long raw[8];
     unsigned err = 0;
@@ -745,6 +872,7 @@ int pt_pass_set_profiling(pt_pass *pass, int enable) {
 int pt_pass_profile(pt_pass *pass, pt_profile *out, int reset) {
     if(!pass || !out) return fail(PT_ERR_INVALID, "pt_pass_profile: null argument");
     HIP_TRY(hipSetDevice(pass->ctx->device));
+    JOIN_TRY(pass->ctx);
     HIP_TRY(hipStreamSynchronize(pass->ctx->stream));
     collect_profile(pass);
     *out = pass->prof;
@@ -764,8 +892,10 @@ int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
     hits->version++;
     hits->shadow_valid = false;
     if(n == 0) return PT_OK;
+    JOIN_TRY(p->ctx);
     unsigned *cnt = static_cast<unsigned *>(p->d_counters.p);
     hipStream_t s = p->ctx->stream;
+    p->cur_stream = s;
     HIP_TRY(hipMemsetAsync(cnt + CNT_INTERSECT, 0, 12, s));
     const TraceScene sc = make_trace_scene(p);
     if(p->traversal_mode == 0 && (rc = p->d_redo_isect.ensure(n * 4))) return rc;

@@ -66,8 +66,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
         a[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if(blockIdx.x == 0 && threadIdx.x == 0) {
-        dp.stats[0] += (unsigned long long)dp.npix;
-        dp.stats[3] += 1ull;
+        atomicAdd(&dp.stats[0], (unsigned long long)dp.npix);
+        atomicAdd(&dp.stats[3], 1ull);
         dp.counters[0] = (unsigned)dp.npix;  // every pixel is in the first queue
     }
 }
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
     const unsigned nthreads = gridDim.x * blockDim.x;
     const bool skyL = P.SkyboxLighting != 0, skyS = P.SkyboxSampling != 0;
 
-    if(blockIdx.x == 0 && threadIdx.x == 0) dp.stats[1] += (unsigned long long)n;
+    if(blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&dp.stats[1], (unsigned long long)n);
 
     for(unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += nthreads) {
         const unsigned i = queue_in ? queue_in[q] : q;

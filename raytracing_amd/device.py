@@ -201,6 +201,10 @@ class PathTracingPass:
         """0 = ordered traversal with exact fallback (default), 1 = reference order only."""
         check(lib.pt_pass_set_traversal(self.h, int(mode)))
 
+    def set_pipeline(self, draws_in_flight):
+        """How many draws may overlap on the device (1..8); outputs do not depend on it."""
+        check(lib.pt_pass_set_pipeline(self.h, int(draws_in_flight)))
+
     def set_profiling(self, enable=True):
         check(lib.pt_pass_set_profiling(self.h, int(enable)))
 
