@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraytracing_amd.so")
+# RAYTRACING_AMD_LIB selects another build of the library (tuning variants made by build.py --variant)
+LIB_PATH = os.environ.get("RAYTRACING_AMD_LIB") or os.path.join(_HERE, "libraytracing_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

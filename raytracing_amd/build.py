@@ -1,6 +1,6 @@
 """Builds raytracing_amd/libraytracing_amd.so in-tree with hipcc for gfx950.
 
-Usage: python -m raytracing_amd.build [--force]
+Usage: python -m raytracing_amd.build [--force] [--variant NAME -DMACRO=VALUE ...]
 
 Host sources are compiled as plain C++ (no device pass); .hip sources are compiled for
 --offload-arch=gfx950.  All translation units use -ffp-contract=off: scene arrays and
@@ -54,23 +54,28 @@ def _headers():
     return out
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=True, variant=None, defines=()):
+    """variant/defines: a tuning build, e.g. variant="r48", defines=["-DRT_FAST_REFILL=48"], written
+    to libraytracing_amd.<variant>.so next to the real one (objects under _obj/<variant>/)."""
+    obj_dir = os.path.join(OBJ, variant) if variant else OBJ
+    lib = os.path.join(HERE, "libraytracing_amd.%s.so" % variant) if variant else LIB
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     hdrs = _headers()
     jobs = []
     objs = []
+    common = [*COMMON, *defines]
     for rel in HOST_SOURCES + DEVICE_SOURCES:
         src = os.path.join(CSRC, rel)
         if not os.path.exists(src):
             raise RuntimeError("missing source " + src)
-        obj = os.path.join(OBJ, rel.replace("/", "_") + ".o")
+        obj = os.path.join(obj_dir, rel.replace("/", "_") + ".o")
         objs.append(obj)
         if force or _newer(src, obj, hdrs):
             if rel.endswith(".hip"):
-                cmd = [hipcc, "--offload-arch=gfx950", *COMMON, "-c", src, "-o", obj]
+                cmd = [hipcc, "--offload-arch=gfx950", *common, "-c", src, "-o", obj]
             else:
-                cmd = [hipcc, "-x", "c++", *COMMON, "-c", src, "-o", obj]
+                cmd = [hipcc, "-x", "c++", *common, "-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):
@@ -84,11 +89,12 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-lpthread"])
-    return LIB
+    if jobs or force or not os.path.exists(lib):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-lpthread"])
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    argv = sys.argv[1:]
+    var = argv[argv.index("--variant") + 1] if "--variant" in argv else None
+    print(build(force="--force" in argv, variant=var, defines=[a for a in argv if a.startswith("-D")]))

@@ -616,10 +616,10 @@ int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
     p->redo_blocks = ctx->num_cus;
     if(!rc) rc = p->d_counters.ensure(CNT_TOTAL * 4);
     if(!rc) rc = p->d_stats.ensure(8 * 8);
-    if(!rc) rc = p->d_err.ensure(16);
+    if(!rc) rc = p->d_err.ensure(64);  // word 0: stack overflow flag; bytes 16..47: traversal counters of RT_TRACE_STATS builds
     if(!rc) {
         hipError_t e = hipMemsetAsync(p->d_stats.p, 0, 64, ctx->stream);
-        if(e == hipSuccess) e = hipMemsetAsync(p->d_err.p, 0, 16, ctx->stream);
+        if(e == hipSuccess) e = hipMemsetAsync(p->d_err.p, 0, 64, ctx->stream);
         if(e == hipSuccess) e = hipMemsetAsync(p->d_counters.p, 0, CNT_TOTAL * 4, ctx->stream);
         if(e != hipSuccess) rc = fail(PT_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
     }
@@ -848,7 +848,11 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     out->rays_extend = raw[1];
     out->rays_shadow = raw[2];
     out->draws = raw[3];
-    if(reset) HIP_TRY(hipMemsetAsync(pass->d_stats.p, 0, 64, pass->ctx->stream));
+    HIP_TRY(hipMemcpy(out->reserved, static_cast<char *>(pass->d_err.p) + 16, 32, hipMemcpyDeviceToHost));
+    if(reset) {
+        HIP_TRY(hipMemsetAsync(pass->d_stats.p, 0, 64, pass->ctx->stream));
+        HIP_TRY(hipMemsetAsync(static_cast<char *>(pass->d_err.p) + 16, 0, 32, pass->ctx->stream));
+    }
     if(err) {
         HIP_TRY(hipMemsetAsync(pass->d_err.p, 0, 16, pass->ctx->stream));
         return fail(PT_ERR_STATE, "traversal stack overflow: a ray needed more deferred nodes than the tree height allows; results of the last calls are incomplete");

@@ -14,7 +14,7 @@
 // So this kernel is free to visit nodes in any order and to cull with cheaper arithmetic,
 // as long as
 //   (1) culling is conservative: boxes are tested with a per-ray reciprocal and the
-//       comparisons are relaxed by 1e-6, eight times the arithmetic's error;
+//       comparisons are relaxed by 1e-6, three times the arithmetic's error;
 //   (2) a hit is accepted only for a candidate: the parent box (and, where a scene node
 //       hands over to an instance, the scene leaf box) is re-tested with the reference's
 //       exact IEEE-division slab test whenever the relaxed test did not pass with the same
@@ -52,6 +52,11 @@ struct FastScene {
     unsigned *error_flag;
 };
 
+// 1/x to one ulp (v_rcp_f32), for the relaxed tests only.  With the subtraction and the
+// product that is at most 2.5 ulp = 3e-7 away from the reference's IEEE quotient, a third of
+// the 1e-6 the comparisons are relaxed by.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // relaxed slab test with a reciprocal direction; tn = entry distance (>= 0)
 __device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float hix, float hiy, float hiz, float ox,
                                           float oy, float oz, float ix, float iy, float iz, float &tn, bool &clear) {
@@ -71,7 +76,20 @@ __device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float
 template <class Source, class Sink>
 __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, Sink &sink, unsigned *next_ray,
                                               unsigned n_rays, uint2 *s_stack) {
-    constexpr int REFILL_BELOW = 40;  // refill when fewer lanes than this still own a ray
+#ifndef RT_FAST_REFILL
+#define RT_FAST_REFILL 48
+#endif
+    constexpr int REFILL_BELOW = RT_FAST_REFILL;  // refill when fewer lanes than this still own a ray
+#ifndef RT_LEAF_BATCH
+#define RT_LEAF_BATCH 8
+#endif
+#ifndef RT_INST_BATCH
+#define RT_INST_BATCH 4
+#endif
+#ifndef RT_SERVE_ALL_BELOW
+#define RT_SERVE_ALL_BELOW 16
+#endif
+    constexpr int LEAF_BATCH = RT_LEAF_BATCH, INST_BATCH = RT_INST_BATCH, SERVE_ALL_BELOW = RT_SERVE_ALL_BELOW;
     const unsigned tid = threadIdx.x;
     const unsigned gtid = blockIdx.x * blockDim.x + tid;
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
@@ -91,6 +109,9 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
     unsigned ref = 0;
     float tn = 0;
 
+#ifdef RT_TRACE_STATS
+    unsigned long long st_slots = 0, st_inner = 0, st_leaf = 0, st_inst = 0;
+#endif
     for(;;) {
         {
             unsigned idx = 0;
@@ -104,20 +125,24 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                     wdx = d[0]; wdy = d[1]; wdz = d[2];
                     cox = wox; coy = woy; coz = woz;
                     cdx = wdx; cdy = wdy; cdz = wdz;
-                    cix = 1.0f / wdx; ciy = 1.0f / wdy; ciz = 1.0f / wdz;
+                    cix = fast_rcp(wdx); ciy = fast_rcp(wdy); ciz = fast_rcp(wdz);
                     in_mesh = false;
                     best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
                     second_t = RT_INF;
                     abs_slack = 1e-6f * (fabsf(wox) + fabsf(woy) + fabsf(woz) + sc.hdr.extent);
                     active = true;
                     sp = 0;
-                    // the scene root's box, exactly (once per ray): it is the scene leaf box
-                    // itself when the scene is a single instance
-                    float t0;
-                    have = slab_test(sc.hdr.root_lo[0], sc.hdr.root_lo[1], sc.hdr.root_lo[2], sc.hdr.root_hi[0],
-                                     sc.hdr.root_hi[1], sc.hdr.root_hi[2], wox, woy, woz, wdx, wdy, wdz, t0);
+                    // a single-instance scene: the root's box is the scene leaf box, whose exact
+                    // test decides candidates; otherwise the boxes below the root imply it
+                    have = true;
+                    tn = 0.0f;
+                    if((sc.hdr.root_ref >> 30) == REF_INSTANCE) {
+                        float t0;
+                        have = slab_test(sc.hdr.root_lo[0], sc.hdr.root_lo[1], sc.hdr.root_lo[2], sc.hdr.root_hi[0],
+                                         sc.hdr.root_hi[1], sc.hdr.root_hi[2], wox, woy, woz, wdx, wdy, wdz, t0);
+                        tn = t0;
+                    }
                     ref = sc.hdr.root_ref;
-                    tn = t0;
                 }
             }
             exhausted = feed.dry;
@@ -149,10 +174,29 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
             if(nact == 0) break;
             if(!drained && nact < REFILL_BELOW) break;
 
-            // ---- one 64-byte fetch per lane, whatever the entry is
+            // ---- which kinds of entry this iteration serves.  Inner nodes always; triangle
+            // leaves and instance entries only once enough lanes hold one (they wait, holding
+            // their entry), because each kind's code runs for the whole wave however few lanes
+            // need it: a ray meets six inner nodes per leaf and ten per instance entry.
             const unsigned kind = ref >> 30, idx = ref & REF_INDEX_MASK;
+            const bool is_leaf = have && kind == REF_TRIANGLE, is_inst = have && kind == REF_INSTANCE;
+            const bool is_inner = have && !is_leaf && !is_inst;
+            const int n_inner = __popcll(__ballot(is_inner));
+            const bool starving = n_inner < SERVE_ALL_BELOW;
+            const bool serve_leaf = starving || __popcll(__ballot(is_leaf)) >= LEAF_BATCH;
+            const bool serve_inst = starving || __popcll(__ballot(is_inst)) >= INST_BATCH;
+            const bool go = is_inner || (is_leaf && serve_leaf) || (is_inst && serve_inst);
+#ifdef RT_TRACE_STATS
+            st_slots += 1;
+            if(go) {
+                if(kind == REF_TRIANGLE) st_leaf++;
+                else if(kind == REF_INSTANCE) st_inst++;
+                else st_inner++;
+            }
+#endif
+            // ---- one 64-byte fetch per served lane, whatever the entry is
             float4 q0, q1, q2, q3;
-            if(have) {
+            if(go) {
                 const char *base = kind == REF_MESH_INNER    ? reinterpret_cast<const char *>(sc.mesh_nodes + idx)
                                    : kind == REF_TRIANGLE    ? reinterpret_cast<const char *>(sc.tri_leaf + idx)
                                    : kind == REF_SCENE_INNER ? reinterpret_cast<const char *>(sc.scene_nodes + idx)
@@ -163,14 +207,14 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 q0 = q1 = q2 = q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             // scene-level entries are met with the world ray
-            if(have && kind >= REF_SCENE_INNER && in_mesh) {
+            if(go && kind >= REF_SCENE_INNER && in_mesh) {
                 cox = wox; coy = woy; coz = woz;
                 cdx = wdx; cdy = wdy; cdz = wdz;
-                cix = 1.0f / wdx; ciy = 1.0f / wdy; ciz = 1.0f / wdz;
+                cix = fast_rcp(wdx); ciy = fast_rcp(wdy); ciz = fast_rcp(wdz);
                 in_mesh = false;
             }
 
-            if(have && (kind == REF_MESH_INNER || kind == REF_SCENE_INNER)) {
+            if(is_inner) {
                 float t0, t1;
                 bool c0clear, c1clear;
                 bool p0 = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, c0clear);
@@ -219,7 +263,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 } else {
                     have = false;
                 }
-            } else if(have && kind == REF_INSTANCE) {
+            } else if(serve_inst && is_inst) {
                 // entry into the instance: rows of world-to-local, then the mesh root
                 cox = (q0.x * wox + q0.y * woy) + (q0.z * woz + q0.w);
                 coy = (q1.x * wox + q1.y * woy) + (q1.z * woz + q1.w);
@@ -227,11 +271,11 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 cdx = (q0.x * wdx + q0.y * wdy) + q0.z * wdz;
                 cdy = (q1.x * wdx + q1.y * wdy) + q1.z * wdz;
                 cdz = (q2.x * wdx + q2.y * wdy) + q2.z * wdz;
-                cix = 1.0f / cdx; ciy = 1.0f / cdy; ciz = 1.0f / cdz;
+                cix = fast_rcp(cdx); ciy = fast_rcp(cdy); ciz = fast_rcp(cdz);
                 in_mesh = true;
                 cur_inst = (int)idx;
                 ref = __float_as_uint(q3.x);  // mesh root; its own box is implied by the boxes below it
-            } else if(have) {
+            } else if(serve_leaf && is_leaf) {
                 // triangle leaf: q0, q1.xy parent box; then v0, e1, e2
                 const float v0x = q1.z, v0y = q1.w, v0z = q2.x;
                 const float e1x = q2.y, e1y = q2.z, e1z = q2.w;
@@ -269,6 +313,13 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
             }
         }
     }
+#ifdef RT_TRACE_STATS
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(sc.error_flag + 4);
+    atomicAdd(dbg + 0, st_slots);
+    atomicAdd(dbg + 1, st_inner);
+    atomicAdd(dbg + 2, st_leaf);
+    atomicAdd(dbg + 3, st_inst);
+#endif
 }
 
 }  // namespace rta

@@ -195,7 +195,7 @@ class PathTracingPass:
         s = PtStats()
         check(lib.pt_pass_stats(self.h, C.byref(s), int(reset)))
         return dict(samples=int(s.samples), rays_extend=int(s.rays_extend), rays_shadow=int(s.rays_shadow),
-                    draws=int(s.draws))
+                    draws=int(s.draws), debug=[int(x) for x in s.reserved])
 
     def set_traversal(self, mode):
         """0 = ordered traversal with exact fallback (default), 1 = reference order only."""

@@ -13,7 +13,7 @@ for f in glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"]
         if sub and sub not in k:
             continue
-        k = k.split("(")[0].split("::")[-1]
+        k = k.replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1]
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k][r["Counter_Name"]] += 1
 for k in tot:
