@@ -122,7 +122,7 @@ def main():
         total_rays = args.rays * steps
         units_per_rank = dict(rays=total_rays, samples=0, rays_extend=total_rays, rays_shadow=0)
         prof = p.profile() if not args.no_profile else None
-        dominant = ("intersect_kernel", prof["intersect_ms"], prof["intersect_launches"], total_rays) if prof else None
+        dominant = ("intersect_fast_kernel + intersect_kernel", prof["intersect_ms"], prof["intersect_launches"], total_rays) if prof else None
     else:
         total_spp = steps * world
         jit = scene.mt19937_jitters(total_spp)
@@ -264,10 +264,21 @@ def main():
             if b_ray is not None:
                 achieved = rays_in_kernel * b_ray / (ms * 1e-3) / 1e9
                 out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_unit": "bytes per launch",
                                    "avg_launch_ms": ms / launches, "launches": int(launches),
                                    "algorithmic_bytes_per_ray": b_ray,
                                    "rays_per_launch": rays_in_kernel / launches}
+            # HBM bytes per launch of the same kernels, from the committed rocprofv3 --pmc passes
+            # (FETCH_SIZE + WRITE_SIZE; bench.py cannot collect counters on itself)
+            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % wl)
+            if "roofline" in out and os.path.exists(pmc_file):
+                pmc = json.load(open(pmc_file))
+                names = ["intersect_fast_kernel", "intersect_kernel"] if wl == "casa_isect" else ["extend_fast_kernel", "extend_kernel"]
+                per = [pmc[n]["hbm_bytes_per_launch"] for n in names if n in pmc and "hbm_bytes_per_launch" in pmc[n]]
+                if per:
+                    out["roofline"]["traffic"] = float(sum(per))
+                    out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_file)
+                    out["roofline"]["algorithmic_bytes_per_launch"] = out["roofline"]["rays_per_launch"] * b_ray
             if prof:
                 out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms")}
                 if "draws" in prof:

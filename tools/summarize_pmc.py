@@ -1,11 +1,21 @@
-"""Sums rocprofv3 --pmc counter CSVs per kernel name.  Usage: summarize_pmc.py <dir> [kernel substring]"""
+"""Sums rocprofv3 --pmc counter CSVs per kernel name.
+Usage: summarize_pmc.py <dir> [kernel substring] [--json out.json]
+With --json, also writes {kernel: {counter: {"total":, "launches":}}} plus HBM bytes per launch
+(FETCH_SIZE and WRITE_SIZE are in KiB; for this library's access pattern -- 64-byte records
+gathered with four 16-byte loads per lane -- tools/calib/fetch_calib.hip measured FETCH_SIZE
+equal to the known byte count, so no gfx950 doubling is applied)."""
 import csv
 import glob
+import json
 import sys
 from collections import defaultdict
 
-d = sys.argv[1]
-sub = sys.argv[2] if len(sys.argv) > 2 else ""
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+d = args[0]
+sub = args[1] if len(args) > 1 and not args[1].endswith(".json") else ""
+jout = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+if jout in args:
+    args.remove(jout)
 tot = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(lambda: defaultdict(int))
 for f in glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True):
@@ -20,3 +30,11 @@ for k in tot:
     print(k)
     for c in sorted(tot[k]):
         print("  %-32s total %.6g  launches %d  per-launch %.6g" % (c, tot[k][c], calls[k][c], tot[k][c] / calls[k][c]))
+if jout:
+    out = {}
+    for k in tot:
+        out[k] = {c: {"total": tot[k][c], "launches": calls[k][c]} for c in tot[k]}
+        if "FETCH_SIZE" in tot[k] and "WRITE_SIZE" in tot[k]:
+            out[k]["hbm_bytes_per_launch"] = (tot[k]["FETCH_SIZE"] / calls[k]["FETCH_SIZE"] +
+                                              tot[k]["WRITE_SIZE"] / calls[k]["WRITE_SIZE"]) * 1024.0
+    json.dump(out, open(jout, "w"), indent=1, sort_keys=True)
