@@ -155,7 +155,8 @@ def main():
         dt = time.perf_counter() - t0
         st = p.stats(reset=True)
         units_per_rank = dict(rays=st["rays_extend"] + st["rays_shadow"], samples=st["samples"],
-                              rays_extend=st["rays_extend"], rays_shadow=st["rays_shadow"])
+                              rays_extend=st["rays_extend"], rays_shadow=st["rays_shadow"],
+                              retraced=st["rays_retraced"])
         # Per-kernel times: the same draws once more, one at a time (overlapping draws would
         # be charged each other's time), bracketed by HIP events on the launching stream.
         prof = dominant = None
@@ -211,6 +212,8 @@ def main():
                        "draws_in_flight": args.pipeline if wl != "casa_isect" else None,
                        "parallelism": "sample slicing x%d, one all-reduce" % world if world > 1 else "single GPU"},
             "msamples_per_s": total_samples / dt / 1e6,
+            "retraced_fraction_of_extend_rays": (units_per_rank.get("retraced", 0) / units_per_rank["rays_extend"])
+                                                if units_per_rank.get("rays_extend") else None,
             "rays_per_sample": (total_rays / total_samples) if total_samples else None,
             "setup_s": setup_s,
         }
@@ -243,15 +246,20 @@ def main():
                 cdt = time.perf_counter() - t1
                 c_rays = cnt["rays_extend"] + cnt["rays_shadow"]
                 b_ray = oracle.algorithmic_bytes_per_extend_ray(cnt)
-                if (sw, sh) == (W, H):
+                if True:
                     # the same sample once more on the GPU, outside the timed region: live parity
-                    p.set_profiling(False)
-                    p.set_params(prm)
-                    p.draw()
-                    got = p.download()
+                    pc = p if (sw, sh) == (W, H) else device.PathTracingPass(ctx, sw, sh)
+                    if pc is not p:
+                        pc.bind_scene(sb)
+                    pc.set_profiling(False)
+                    pc.set_params(prm)
+                    pc.draw()
+                    got = pc.download()
+                    if pc is not p:
+                        pc.destroy()
                     same = all(bool(np.all((got[k].view(np.uint32) == ref[k].view(np.uint32)) | (got[k] == ref[k])
                                            | (np.isnan(got[k]) & np.isnan(ref[k])))) for k in ref)
-                    out["parity_vs_oracle"] = ("all 7 outputs bit-equal for sample %d at %dx%d" % (s_last, W, H)) if same else "MISMATCH"
+                    out["parity_vs_oracle"] = ("all 7 outputs bit-equal for sample %d at %dx%d" % (s_last, sw, sh)) if same else "MISMATCH"
                 out["cpu_baseline"] = {"value": c_rays / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
                                        "sample": "1 spp of the same frame at %dx%d (%d rays), OpenMP over rows" % (sw, sh, c_rays)}
                 out["algorithmic_bytes"] = {"per_extend_ray": b_ray,

@@ -153,7 +153,8 @@ typedef struct pt_stats {
     uint64_t rays_extend;    /* closest-hit queries: primary + indirect           */
     uint64_t rays_shadow;    /* occlusion queries: sky NEE + light shadow rays    */
     uint64_t draws;
-    uint64_t reserved[4];
+    uint64_t rays_retraced;  /* closest-hit queries the ordered traversal handed to the reference-order one */
+    uint64_t reserved[3];
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 
@@ -198,6 +199,31 @@ typedef struct pt_hit {
 } pt_hit;
 int pt_pass_intersect(pt_pass *pass, const pt_buf *rays, size_t n, pt_buf *hits);
 
+/* ---- post-processing: the consumers of the pass's outputs that produce a viewable image ----
+ * All buffers hold floats, 3 per pixel unless stated; npix is taken from the buffer sizes,
+ * which must agree.  Each call is queued behind the draws issued before it.
+ *
+ * pt_post_merge: color = (direct + indirect) * albedo, NaN or Inf in any channel -> 10000 in
+ *   all three (shader/postprocessing/SVGF_Merge.glsl:24-52; SVGF_Merge::draw,
+ *   src/renderpass/SVGF_Merge.cpp).
+ * pt_post_static_blend: running mean of `color` into history_color across frames with 3-sigma
+ *   luminance firefly rejection; history_moment holds 2 floats per pixel (mean luminance and
+ *   mean squared luminance).  frame_counter is the value the reference's StaticBlender::draw
+ *   passes after its ++frameCounter: 1 for the first frame (StaticBlender.glsl:26-61,
+ *   StaticBlender.cpp:17-27).
+ * pt_post_tonemap: ACES curve then pow(x, 0.45) per channel (ToneMappingGamma.glsl:17-54);
+ *   out may be the same buffer as color. */
+int pt_post_merge(pt_ctx *ctx, const pt_buf *direct, const pt_buf *indirect, const pt_buf *albedo, pt_buf *color);
+int pt_post_static_blend(pt_ctx *ctx, uint32_t frame_counter, const pt_buf *color, pt_buf *history_color,
+                         pt_buf *history_moment);
+int pt_post_tonemap(pt_ctx *ctx, const pt_buf *color, pt_buf *out);
+
+/* SSBOBuffer<float>::save_as_image (src/SSBOBuffer.h:41-62): bytes = min(255, int(x * 255)),
+ * rows flipped (buffers hold the bottom row first), written as an 8-bit PNG (the reference
+ * lets OpenCV pick the format from the file name; only PNG is written here).  channel is 1, 3
+ * or 4 and width * height * channel floats must be the buffer's size. */
+int pt_buf_save_as_image(const pt_buf *buf, int width, int height, int channel, const char *path);
+
 /* ---- host-side scene helpers (no GPU) ------------------------------------------------ */
 /* Mesh::build_meshBVH + ResourceManager::reload_meshes, src/instance/Mesh.cpp:10-22,
  * src/ResourceManager.cpp:95-140.  tris: concatenated 96-byte triangles, tri_count[m]
@@ -228,6 +254,12 @@ int pt_host_rgbe_decode(const void *bytes, size_t n, int32_t *w, int32_t *h, flo
 int64_t pt_host_rgbe_encode(const float *rgb, int32_t w, int32_t h, void *out, size_t cap);
 /* Skybox::load_to_gpu's CPU half, src/texture/Skybox.cpp:12-53 */
 int pt_host_sky_cache(const float *rgb, int32_t w, int32_t h, float *cache_out, double *light_sum_out);
+
+/* The host half of save_as_image: quantise + flip `data` (height rows of width*channel floats,
+ * bottom row first) into `pixels_out` (height*width*channel bytes, top row first), and write
+ * top-row-first bytes as a PNG. */
+int pt_host_quantize_image(const float *data, int32_t width, int32_t height, int32_t channel, uint8_t *pixels_out);
+int pt_host_write_png(const char *path, int32_t width, int32_t height, int32_t channel, const uint8_t *pixels);
 
 #ifdef __cplusplus
 }

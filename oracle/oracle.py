@@ -73,6 +73,14 @@ def lib():
         _lib.orc_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         _lib.orc_render.restype = None
         _lib.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.orc_post_merge.restype = None
+        _lib.orc_post_merge.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_post_static_blend.restype = None
+        _lib.orc_post_static_blend.argtypes = [C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_post_tonemap.restype = None
+        _lib.orc_post_tonemap.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
+        _lib.orc_quantize_image.restype = None
+        _lib.orc_quantize_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return _lib
 
 
@@ -134,6 +142,39 @@ class OracleScene:
         cnt = OrcCounters()
         lib().orc_render(C.addressof(self.c), C.addressof(params), C.addressof(o), C.addressof(cnt), n_threads)
         return out, cnt.as_dict()
+
+
+def post_merge(di, idi, albedo):
+    """SVGF_Merge: (di + idi) * albedo with the NaN/Inf replacement; arrays of 3 floats per pixel."""
+    di, idi, albedo = (np.ascontiguousarray(a, np.float32).ravel() for a in (di, idi, albedo))
+    out = np.zeros_like(di)
+    lib().orc_post_merge(di.size // 3, di.ctypes.data, idi.ctypes.data, albedo.ctypes.data, out.ctypes.data)
+    return out
+
+
+def post_static_blend(frame, color, hist_color, hist_moment):
+    """StaticBlender: returns the updated (history colour, history moment)."""
+    color = np.ascontiguousarray(color, np.float32).ravel()
+    hc = np.array(hist_color, np.float32).ravel().copy()
+    hm = np.array(hist_moment, np.float32).ravel().copy()
+    lib().orc_post_static_blend(color.size // 3, int(frame), color.ctypes.data, hc.ctypes.data, hm.ctypes.data)
+    return hc, hm
+
+
+def post_tonemap(color):
+    color = np.ascontiguousarray(color, np.float32).ravel()
+    out = np.zeros_like(color)
+    lib().orc_post_tonemap(color.size, color.ctypes.data, out.ctypes.data)
+    return out
+
+
+def quantize_image(data, w, h, c):
+    """save_as_image's bytes: (h, w, c) uint8, top row first."""
+    data = np.ascontiguousarray(data, np.float32).ravel()
+    assert data.size == w * h * c
+    out = np.zeros(w * h * c, np.uint8)
+    lib().orc_quantize_image(data.ctypes.data, w, h, c, out.ctypes.data)
+    return out.reshape(h, w, c)
 
 
 def algorithmic_bytes_per_ray(cnt):

@@ -952,4 +952,56 @@ float orc_skybox_sample_pdf(const orc_scene *scene, const orc_params *params, co
     return c.skybox_sample_pdf(vec3(dir[0], dir[1], dir[2]));
 }
 
+// SVGF_Merge.glsl:24-52
+void orc_post_merge(size_t npix, const float *di, const float *idi, const float *albedo, float *color) {
+    for(size_t i = 0; i < npix; i++) {
+        vec3 d(di[i * 3], di[i * 3 + 1], di[i * 3 + 2]), id(idi[i * 3], idi[i * 3 + 1], idi[i * 3 + 2]);
+        vec3 al(albedo[i * 3], albedo[i * 3 + 1], albedo[i * 3 + 2]);
+        vec3 result = (d + id) * al;
+        if(std::isnan(result.x) || std::isnan(result.y) || std::isnan(result.z)) result = vec3(10000.0f);
+        if(std::isinf(result.x) || std::isinf(result.y) || std::isinf(result.z)) result = vec3(10000.0f);
+        color[i * 3] = result.x; color[i * 3 + 1] = result.y; color[i * 3 + 2] = result.z;
+    }
+}
+
+// StaticBlender.glsl:22-61
+void orc_post_static_blend(size_t npix, uint32_t frame, const float *colorbuf, float *hist_color, float *hist_moment) {
+    for(size_t i = 0; i < npix; i++) {
+        vec3 color(colorbuf[i * 3], colorbuf[i * 3 + 1], colorbuf[i * 3 + 2]);
+        float lum = color.x * 0.212671f + color.y * 0.715160f + color.z * 0.072169f;
+        float mx = lum, my = lum * lum;
+        vec3 lastcolor(hist_color[i * 3], hist_color[i * 3 + 1], hist_color[i * 3 + 2]);
+        float lmx = hist_moment[i * 2], lmy = hist_moment[i * 2 + 1];
+        float sigma = std::sqrt(std::fmax(1.0f, lmy - lmx * lmx));
+        float a = 1.0f / (float)frame;
+        if(frame != 1u && std::fabs(mx - lmx) > sigma * 3.0f) color = lastcolor;
+        else color = mixv(lastcolor, color, a);
+        hist_color[i * 3] = color.x; hist_color[i * 3 + 1] = color.y; hist_color[i * 3 + 2] = color.z;
+        hist_moment[i * 2] = mixf(lmx, mx, a);
+        hist_moment[i * 2 + 1] = mixf(lmy, my, a);
+    }
+}
+
+// ToneMappingGamma.glsl:17-54 (ACES, then pow 0.45 per channel)
+void orc_post_tonemap(size_t n, const float *in, float *out) {
+    const float A = 2.51f, B = 0.03f, C = 2.43f, D = 0.59f, E = 0.14f;
+    for(size_t i = 0; i < n; i++) {
+        float c = in[i];
+        float t = (c * (A * c + B)) / (c * (C * c + D) + E);
+        out[i] = m_pow(t, 0.45f);
+    }
+}
+
+// src/SSBOBuffer.h:47-56: datau = min(255, int(x * 255)) as a byte, then cv::flip(img, img, 0)
+void orc_quantize_image(const float *data, int w, int h, int c, uint8_t *out) {
+    const size_t row = (size_t)w * c;
+    for(int y = 0; y < h; y++)
+        for(size_t k = 0; k < row; k++) {
+            float x = data[row * (size_t)(h - 1 - y) + k] * 255.0f;
+            long long v = std::isnan(x) ? 0 : (x >= 2147483520.0f ? 2147483647ll : (x <= -2147483648.0f ? -2147483648ll : (long long)(int)x));
+            if(v > 255) v = 255;
+            out[row * (size_t)y + k] = (uint8_t)(unsigned long long)v;
+        }
+}
+
 }  // extern "C"

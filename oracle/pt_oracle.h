@@ -131,6 +131,14 @@ void orc_background(const orc_scene *scene, const float dir[3], float out[3]);
 void orc_skybox_sample(const orc_scene *scene, const orc_params *params, uint32_t seed, uint32_t dim, float out[4]);
 float orc_skybox_sample_pdf(const orc_scene *scene, const orc_params *params, const float dir[3]);
 
+/* The element-wise consumers of the outputs:
+ * SVGF_Merge.glsl:24-52, StaticBlender.glsl:26-61, ToneMappingGamma.glsl:17-54 and the
+ * float -> byte + flip step of SSBOBuffer::save_as_image (src/SSBOBuffer.h:47-56). */
+void orc_post_merge(size_t npix, const float *di, const float *idi, const float *albedo, float *color);
+void orc_post_static_blend(size_t npix, uint32_t frame, const float *color, float *hist_color, float *hist_moment);
+void orc_post_tonemap(size_t n, const float *in, float *out);
+void orc_quantize_image(const float *data, int w, int h, int c, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,7 +47,7 @@ class PtParams(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64), ("rays_extend", C.c_uint64), ("rays_shadow", C.c_uint64),
-        ("draws", C.c_uint64), ("reserved", C.c_uint64 * 4),
+        ("draws", C.c_uint64), ("rays_retraced", C.c_uint64), ("reserved", C.c_uint64 * 3),
     ]
 
 
@@ -87,6 +87,12 @@ SIGNATURES = {
     "pt_pass_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats), C.c_int]),
     "pt_pass_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_post_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_post_static_blend": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_post_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_buf_save_as_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]),
+    "pt_host_quantize_image": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "pt_host_write_png": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pt_pass_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_profile": (C.c_int, [C.c_void_p, C.POINTER(PtProfile), C.c_int]),
     "pt_pass_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

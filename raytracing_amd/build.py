@@ -23,11 +23,13 @@ HOST_SOURCES = [
     "host/scene_host.cpp",
     "host/sky_host.cpp",
     "host/accel_layout.cpp",
+    "host/png_writer.cpp",
 ]
 DEVICE_SOURCES = [
     "capi_device.hip",
     "device/trace_kernels.hip",
     "device/path_kernels.hip",
+    "device/post_kernels.hip",
 ]
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result"]

@@ -9,6 +9,7 @@
 #include "device/kernels.h"
 #include "device/trace_fast.h"
 #include "host/accel_layout.h"
+#include "host/png_writer.h"
 #include "host/scene_types.h"
 
 using namespace rta;
@@ -735,6 +736,7 @@ int pt_pass_draw(pt_pass *p) {
     dp.stats = static_cast<unsigned long long *>(p->d_stats.p);
     unsigned *cnt = static_cast<unsigned *>(L.counters.p);
     dp.counters = cnt;
+    dp.redo_counter_base = p->traversal_mode == 0 ? CNT_REDO : -1;
 
     hipStream_t s = L.stream;
     p->cur_stream = s;
@@ -848,7 +850,8 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     out->rays_extend = raw[1];
     out->rays_shadow = raw[2];
     out->draws = raw[3];
-    HIP_TRY(hipMemcpy(out->reserved, static_cast<char *>(pass->d_err.p) + 16, 32, hipMemcpyDeviceToHost));
+    out->rays_retraced = raw[4];
+    HIP_TRY(hipMemcpy(out->reserved, static_cast<char *>(pass->d_err.p) + 16, 24, hipMemcpyDeviceToHost));
     if(reset) {
         HIP_TRY(hipMemsetAsync(pass->d_stats.p, 0, 64, pass->ctx->stream));
         HIP_TRY(hipMemsetAsync(static_cast<char *>(pass->d_err.p) + 16, 0, 32, pass->ctx->stream));
@@ -919,6 +922,76 @@ int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
         }
     }
     HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------- post-processing
+int pt_post_merge(pt_ctx *ctx, const pt_buf *direct, const pt_buf *indirect, const pt_buf *albedo, pt_buf *color) {
+    if(!ctx || !direct || !indirect || !albedo || !color) return fail(PT_ERR_INVALID, "pt_post_merge: null argument");
+    if(direct->ctx != ctx || indirect->ctx != ctx || albedo->ctx != ctx || color->ctx != ctx)
+        return fail(PT_ERR_INVALID, "pt_post_merge: buffers belong to another context");
+    if(direct->bytes != color->bytes || indirect->bytes != color->bytes || albedo->bytes != color->bytes || color->bytes % 12)
+        return fail(PT_ERR_INVALID, "pt_post_merge: the four buffers must have the same size, 3 floats per pixel");
+    if(color->bytes / 12 > 0x7FFFFFFFull) return fail(PT_ERR_INVALID, "pt_post_merge: too many pixels");
+    HIP_TRY(hipSetDevice(ctx->device));
+    JOIN_TRY(ctx);
+    color->version++;
+    color->shadow_valid = false;
+    if(color->bytes)
+        launch_post_merge(ctx->stream, (int)(color->bytes / 12), static_cast<const float *>(direct->dptr),
+                          static_cast<const float *>(indirect->dptr), static_cast<const float *>(albedo->dptr),
+                          static_cast<float *>(color->dptr));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_post_static_blend(pt_ctx *ctx, uint32_t frame_counter, const pt_buf *color, pt_buf *history_color, pt_buf *history_moment) {
+    if(!ctx || !color || !history_color || !history_moment) return fail(PT_ERR_INVALID, "pt_post_static_blend: null argument");
+    if(color->ctx != ctx || history_color->ctx != ctx || history_moment->ctx != ctx)
+        return fail(PT_ERR_INVALID, "pt_post_static_blend: buffers belong to another context");
+    if(frame_counter == 0) return fail(PT_ERR_INVALID, "pt_post_static_blend: frame_counter starts at 1");
+    if(color->bytes % 12 || history_color->bytes != color->bytes || history_moment->bytes != color->bytes / 12 * 8)
+        return fail(PT_ERR_INVALID, "pt_post_static_blend: color and history_color hold 3 floats per pixel, history_moment 2");
+    if(color->bytes / 12 > 0x7FFFFFFFull) return fail(PT_ERR_INVALID, "pt_post_static_blend: too many pixels");
+    HIP_TRY(hipSetDevice(ctx->device));
+    JOIN_TRY(ctx);
+    for(pt_buf *b : {history_color, history_moment}) {
+        b->version++;
+        b->shadow_valid = false;
+    }
+    if(color->bytes)
+        launch_post_static_blend(ctx->stream, (int)(color->bytes / 12), frame_counter, static_cast<const float *>(color->dptr),
+                                 static_cast<float *>(history_color->dptr), static_cast<float *>(history_moment->dptr));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_post_tonemap(pt_ctx *ctx, const pt_buf *color, pt_buf *out) {
+    if(!ctx || !color || !out) return fail(PT_ERR_INVALID, "pt_post_tonemap: null argument");
+    if(color->ctx != ctx || out->ctx != ctx) return fail(PT_ERR_INVALID, "pt_post_tonemap: buffers belong to another context");
+    if(color->bytes != out->bytes || color->bytes % 4) return fail(PT_ERR_INVALID, "pt_post_tonemap: buffers must have the same size");
+    HIP_TRY(hipSetDevice(ctx->device));
+    JOIN_TRY(ctx);
+    out->version++;
+    out->shadow_valid = false;
+    if(out->bytes) launch_post_tonemap(ctx->stream, out->bytes / 4, static_cast<const float *>(color->dptr), static_cast<float *>(out->dptr));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_buf_save_as_image(const pt_buf *buf, int width, int height, int channel, const char *path) {
+    if(!buf || !path) return fail(PT_ERR_INVALID, "pt_buf_save_as_image: null argument");
+    if(width <= 0 || height <= 0 || (channel != 1 && channel != 3 && channel != 4))
+        return fail(PT_ERR_INVALID, "pt_buf_save_as_image: width/height must be positive and channel 1, 3 or 4");
+    if((size_t)width * height * channel * sizeof(float) != buf->bytes)
+        return fail(PT_ERR_INVALID, "pt_buf_save_as_image: width * height * channel floats is not the buffer's size");
+    std::vector<float> host((size_t)width * height * channel);
+    int rc = pt_buf_download(buf, host.data(), buf->bytes);
+    if(rc) return rc;
+    std::vector<uint8_t> px;
+    quantize_flip(host.data(), width, height, channel, px);
+    std::string err;
+    if(!write_png(path, width, height, channel, px.data(), err)) return fail(PT_ERR_INVALID, err);
     return PT_OK;
 }
 

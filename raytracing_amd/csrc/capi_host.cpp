@@ -6,6 +6,7 @@
 #include "host/bvh_builder.h"
 #include "host/scene_host.h"
 #include "host/sky_host.h"
+#include "host/png_writer.h"
 
 namespace rta {
 static thread_local std::string g_last_error;
@@ -139,6 +140,22 @@ int pt_host_sky_cache(const float *rgb, int32_t w, int32_t h, float *cache_out, 
     std::vector<float> cache;
     sky_build_cache(rgb, w, h, cache, *light_sum_out);
     memcpy(cache_out, cache.data(), cache.size() * sizeof(float));
+    return PT_OK;
+}
+
+int pt_host_quantize_image(const float *data, int32_t width, int32_t height, int32_t channel, uint8_t *pixels_out) {
+    if(!data || !pixels_out || width <= 0 || height <= 0 || (channel != 1 && channel != 3 && channel != 4))
+        return fail(PT_ERR_INVALID, "pt_host_quantize_image: bad argument");
+    std::vector<uint8_t> tmp;
+    rta::quantize_flip(data, width, height, channel, tmp);
+    memcpy(pixels_out, tmp.data(), tmp.size());
+    return PT_OK;
+}
+
+int pt_host_write_png(const char *path, int32_t width, int32_t height, int32_t channel, const uint8_t *pixels) {
+    if(!path) return fail(PT_ERR_INVALID, "pt_host_write_png: null path");
+    std::string err;
+    if(!rta::write_png(path, width, height, channel, pixels, err)) return fail(PT_ERR_INVALID, err);
     return PT_OK;
 }
 

@@ -31,8 +31,9 @@ struct DrawParams {
     ShadowEntry *shadow;  // [n_shadow][npix]
     // outputs
     float *o_direct, *o_indirect, *o_albedo, *o_motion, *o_depth, *o_normal, *o_inst;
-    // counters: [0] samples, [1] extend rays, [2] shadow rays, [3] draws
+    // counters: [0] samples, [1] extend rays, [2] shadow rays, [3] draws, [4] extend rays re-traced in reference order
     unsigned long long *stats;
+    int redo_counter_base;  // index in `counters` of the per-vertex re-trace counts, -1 when there are none
     // per-draw queue counters, zeroed before generate: [d] = paths alive at vertex d
     unsigned *counters;
 };
@@ -67,5 +68,10 @@ void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,
                          const unsigned *shadow_count);
 void launch_finalize(hipStream_t s, const DrawParams &dp);
+
+// post-processing (post_kernels.hip)
+void launch_post_merge(hipStream_t s, int npix, const float *di, const float *idi, const float *albedo, float *color);
+void launch_post_tonemap(hipStream_t s, size_t n, const float *in, float *out);
+void launch_post_static_blend(hipStream_t s, int npix, unsigned frame, const float *color, float *hist_color, float *hist_moment);
 
 }  // namespace rta

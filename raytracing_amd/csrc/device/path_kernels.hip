@@ -89,7 +89,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
     const unsigned nthreads = gridDim.x * blockDim.x;
     const bool skyL = P.SkyboxLighting != 0, skyS = P.SkyboxSampling != 0;
 
-    if(blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&dp.stats[1], (unsigned long long)n);
+    if(blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&dp.stats[1], (unsigned long long)n);
+        if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
+    }
 
     for(unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += nthreads) {
         const unsigned i = queue_in ? queue_in[q] : q;

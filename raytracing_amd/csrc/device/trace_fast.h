@@ -316,9 +316,8 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
 #ifdef RT_TRACE_STATS
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(sc.error_flag + 4);
     atomicAdd(dbg + 0, st_slots);
-    atomicAdd(dbg + 1, st_inner);
+    atomicAdd(dbg + 1, st_inner + st_inst);
     atomicAdd(dbg + 2, st_leaf);
-    atomicAdd(dbg + 3, st_inst);
 #endif
 }
 

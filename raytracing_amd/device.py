@@ -89,10 +89,28 @@ class Buffer:
         check(lib.pt_buf_download(self.h, out.ctypes.data, out.nbytes))
         return out
 
+    def save_as_image(self, width, height, channel, path):
+        check(lib.pt_buf_save_as_image(self.h, int(width), int(height), int(channel), str(path).encode()))
+
     def release(self):
         if self.h and self.owned:
             lib.pt_buf_release(self.h)
         self.h = None
+
+
+def post_merge(ctx, direct, indirect, albedo, color):
+    """SVGF_Merge::draw: color = (direct + indirect) * albedo."""
+    check(lib.pt_post_merge(ctx.h, direct.h, indirect.h, albedo.h, color.h))
+
+
+def post_static_blend(ctx, frame_counter, color, history_color, history_moment):
+    """StaticBlender::draw with the frame counter it would pass (1 on the first frame)."""
+    check(lib.pt_post_static_blend(ctx.h, int(frame_counter), color.h, history_color.h, history_moment.h))
+
+
+def post_tonemap(ctx, color, out):
+    """ToneMappingGamma::draw."""
+    check(lib.pt_post_tonemap(ctx.h, color.h, out.h))
 
 
 class Texture:
@@ -195,7 +213,7 @@ class PathTracingPass:
         s = PtStats()
         check(lib.pt_pass_stats(self.h, C.byref(s), int(reset)))
         return dict(samples=int(s.samples), rays_extend=int(s.rays_extend), rays_shadow=int(s.rays_shadow),
-                    draws=int(s.draws), debug=[int(x) for x in s.reserved])
+                    draws=int(s.draws), rays_retraced=int(s.rays_retraced), debug=[int(x) for x in s.reserved])
 
     def set_traversal(self, mode):
         """0 = ordered traversal with exact fallback (default), 1 = reference order only."""
