@@ -96,7 +96,26 @@ def build(force=False, verbose=True, variant=None, defines=()):
     return lib
 
 
+def build_facade_demo(verbose=True):
+    """tests/cpp/facade_frame: the C++ program that drives include/raytracing_amd.hpp."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "cpp", "facade_frame.cpp")
+    exe = os.path.join(root, "tests", "cpp", "facade_frame")
+    hdrs = [os.path.join(root, "include", "raytracing_amd.hpp"), os.path.join(root, "include", "raytracing_amd.h"), LIB]
+    if _newer(src, exe, hdrs):
+        cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "include"), src, "-L" + HERE, "-lraytracing_amd",
+               "-Wl,-rpath,$ORIGIN/../../raytracing_amd", "-o", exe]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("compile failed:\n" + r.stdout + r.stderr)
+    return exe
+
+
 if __name__ == "__main__":
     argv = sys.argv[1:]
     var = argv[argv.index("--variant") + 1] if "--variant" in argv else None
     print(build(force="--force" in argv, variant=var, defines=[a for a in argv if a.startswith("-D")]))
+    if var is None:
+        print(build_facade_demo())

@@ -45,3 +45,13 @@ def test_param_struct_sizes_match_between_binding_and_oracle():
     # pt_params: 2+1+1+16+4+1+2+1+1+2+16+4+1+1+7 = 60 words
     assert ctypes.sizeof(_capi.PtParams) == 60 * 4
     assert ctypes.sizeof(_capi.PtStats) == 64
+
+
+def test_cpp_facade_compiles():
+    """include/raytracing_amd.hpp (the reference's class names over the C ABI) and its C++ user
+    compile as C++17 with warnings as errors; running it needs a GPU (tests/test_gpu_facade.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "tests", "cpp", "facade_frame.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
