@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--tris", type=int, default=10_000_000, help="synth_pt: triangle count")
     ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
     ap.add_argument("--pipeline", type=int, default=3, help="draws in flight on the device (pt_pass_set_pipeline)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank control flow on ONE GPU: all ranks use device 0, gloo backend, collectives staged through the host")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the final output buffers to this .npz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel events (no roofline)")
     return ap.parse_args()
@@ -68,10 +71,15 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the pass has no CPU path)")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from raytracing_amd import device, multigpu, scene
 
@@ -150,10 +158,12 @@ def main():
             draw(s, accum_mode)
         if world > 1:
             ctx.synchronize()
-            multigpu.allreduce_outputs(torch, dist, p, npix, total_spp, dev_tensor)
+            multigpu.allreduce_outputs(torch, dist, p, npix, total_spp, dev_tensor, via_cpu=args.rehearse)
         barrier()
         dt = time.perf_counter() - t0
         st = p.stats(reset=True)
+        if args.dump and rank == 0:
+            np.savez(args.dump, **p.download())
         units_per_rank = dict(rays=st["rays_extend"] + st["rays_shadow"], samples=st["samples"],
                               rays_extend=st["rays_extend"], rays_shadow=st["rays_shadow"],
                               retraced=st["rays_retraced"])
@@ -180,10 +190,11 @@ def main():
 
     # max time over ranks, sum of units over ranks
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        red_dev = "cpu" if args.rehearse else "cuda"
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        uu = torch.tensor([units_per_rank["rays"], units_per_rank["samples"]], dtype=torch.float64, device="cuda")
+        uu = torch.tensor([units_per_rank["rays"], units_per_rank["samples"]], dtype=torch.float64, device=red_dev)
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
         total_rays, total_samples = float(uu[0].item()), float(uu[1].item())
     else:

@@ -29,24 +29,43 @@ def owner_of_last_sample(total_spp, world):
     return (total_spp - 1) % world
 
 
-def combine(dist, tensors, total_spp, world, torch):
+def combine(dist, tensors, total_spp, world, torch, via_cpu=False):
     """tensors: dict name -> flat float32 tensor holding this rank's sums (ACCUMULATED) and
-    last-write values (LAST_WRITE).  In place: afterwards every rank holds the frame."""
+    last-write values (LAST_WRITE).  In place: afterwards every rank holds the frame.
+    Two collectives per frame: ONE all-reduce(sum) over the nine accumulated floats per pixel
+    (staged through one contiguous tensor; the outputs are separate allocations) and one
+    broadcast of the seven last-write floats per pixel from the rank that rendered the last
+    sample.  via_cpu stages them through host memory, for backends without device support
+    (gloo rehearsals of the GPU path)."""
     owner = owner_of_last_sample(total_spp, world)
+    acc = torch.cat([tensors[name] for name in ACCUMULATED])
+    buf = acc.cpu() if via_cpu else acc
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    acc = buf.to(acc.device) if via_cpu else buf
+    acc.mul_(1.0 / float(total_spp))
+    off = 0
     for name in ACCUMULATED:
-        dist.all_reduce(tensors[name], op=dist.ReduceOp.SUM)
-        tensors[name].mul_(1.0 / float(total_spp))
+        n = tensors[name].numel()
+        tensors[name].copy_(acc[off:off + n])
+        off += n
+    last = torch.cat([tensors[name] for name in LAST_WRITE])
+    buf = last.cpu() if via_cpu else last
+    dist.broadcast(buf, src=owner)
+    last = buf.to(last.device) if via_cpu else buf
+    off = 0
     for name in LAST_WRITE:
-        dist.broadcast(tensors[name], src=owner)
+        n = tensors[name].numel()
+        tensors[name].copy_(last[off:off + n])
+        off += n
     return tensors
 
 
-def allreduce_outputs(torch, dist, pass_, npix, total_spp, dev_tensor):
+def allreduce_outputs(torch, dist, pass_, npix, total_spp, dev_tensor, via_cpu=False):
     """GPU form: wraps the pass's output buffers as torch tensors (no copy) and combines
     them over the default process group (RCCL)."""
     world = dist.get_world_size()
     tensors = {}
     for name, c in CHANNELS.items():
         tensors[name] = dev_tensor(torch, pass_.outputs[name].device_ptr, npix * c)
-    combine(dist, tensors, total_spp, world, torch)
+    combine(dist, tensors, total_spp, world, torch, via_cpu=via_cpu)
     torch.cuda.synchronize()
