@@ -25,6 +25,11 @@ import time
 
 import numpy as np
 
+# More hardware queues than HIP's default of 4, so that more draws can overlap on the device
+# (read once, when the HIP runtime starts: before torch is imported).
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -42,7 +47,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tris", type=int, default=10_000_000, help="synth_pt: triangle count")
     ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
-    ap.add_argument("--pipeline", type=int, default=3, help="draws in flight on the device (pt_pass_set_pipeline)")
+    ap.add_argument("--pipeline", type=int, default=6, help="draws in flight on the device (pt_pass_set_pipeline)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank control flow on ONE GPU: all ranks use device 0, gloo backend, collectives staged through the host")
     ap.add_argument("--dump", default=None, help="rank 0 writes the final output buffers to this .npz")

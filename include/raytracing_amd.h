@@ -165,7 +165,7 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
  *   1 the reference's visiting order for every ray (shader/pathtracing.glsl:254-316). */
 int pt_pass_set_traversal(pt_pass *pass, int mode);
 
-/* How many draws may be in flight on the device at once (1..8, default 3); no counterpart in
+/* How many draws may be in flight on the device at once (1..16, default 3); no counterpart in
  * the reference, whose GL driver queues frames by itself.  pt_pass_draw returns as soon as
  * the draw is queued; consecutive draws run on separate HIP streams with path state of their
  * own, so the thin late bounces of one overlap the wide early bounces of the next.  The

@@ -130,7 +130,7 @@ struct pt_pass {
         int spill_depth = 0;
         hipEvent_t done = nullptr, gbuf = nullptr, fin = nullptr, start = nullptr;
     };
-    static constexpr int MAX_LANES = 8;
+    static constexpr int MAX_LANES = 16;
     Lane lanes[MAX_LANES];
     int n_lanes = 3;
     int next_lane = 0;

@@ -8,6 +8,13 @@
 namespace rta {
 namespace {
 
+// Occupancy hint for the ordered kernels (waves per SIMD the register allocator aims for).
+#ifdef RT_FAST_WAVES
+#define RT_FAST_OCC __attribute__((amdgpu_waves_per_eu(RT_FAST_WAVES, RT_FAST_WAVES)))
+#else
+#define RT_FAST_OCC
+#endif
+
 // ---- stand-alone closest hit -----------------------------------------------------------
 // `redo`, when given, lists the ray indices to trace (the ordered kernel's undecided rays).
 struct RaySource {
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void intersect_kernel(TraceScene sc, c
     trace_persistent(sc, src, sink, next_counter, redo ? *redo_count : n, s_stack);
 }
 
-__global__ __launch_bounds__(FAST_BLOCK) void intersect_fast_kernel(FastScene sc, const float *rays, unsigned n,
+__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void intersect_fast_kernel(FastScene sc, const float *rays, unsigned n,
                                                                     pt_hit *hits, unsigned *next_counter,
                                                                     unsigned *redo, unsigned *redo_count) {
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void extend_kernel(TraceScene sc, cons
     trace_persistent(sc, src, sink, next_counter, *count, s_stack);
 }
 
-__global__ __launch_bounds__(FAST_BLOCK) void extend_fast_kernel(FastScene sc, const unsigned *queue,
+__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_fast_kernel(FastScene sc, const unsigned *queue,
                                                                  const unsigned *count, const PathRay *rays,
                                                                  PathHit *hits, unsigned *next_counter,
                                                                  unsigned *redo, unsigned *redo_count) {
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void shadow_kernel(TraceScene sc, cons
 }
 
 // sky-only form (n_shadow == 1): every query is an occlusion query
-__global__ __launch_bounds__(FAST_BLOCK) void shadow_fast_kernel(FastScene sc, const unsigned *queue,
+__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_fast_kernel(FastScene sc, const unsigned *queue,
                                                                  const unsigned *count, const PathRay *rays,
                                                                  ShadowEntry *shadow, int npix,
                                                                  unsigned *next_counter) {
