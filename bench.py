@@ -191,7 +191,12 @@ def main():
             p.set_pipeline(args.pipeline)
             prof["draws"] = n_prof
             prof["serial_ms_per_step"] = serial_ms
-            dominant = ("extend_fast_kernel + extend_kernel", prof["extend_ms"], prof["extend_launches"], pst["rays_extend"])
+            # every BVH traversal launch of the draws: extend at vertex 0, then per vertex one launch
+            # tracing shadow(d) + extend(d+1) rays, each followed by the small reference-order re-trace
+            dominant = ("path_trace_fast_kernel + extend_fast_kernel + extend_kernel",
+                        prof["extend_ms"] + prof["trace_ms"] + prof["shadow_ms"],
+                        prof["extend_launches"] + prof["trace_launches"] + prof["shadow_launches"],
+                        pst["rays_extend"] + pst["rays_shadow"])
 
     # max time over ranks, sum of units over ranks
     if world > 1:
@@ -261,7 +266,7 @@ def main():
                 ref, cnt = osc.render(prm, n_threads=cores)
                 cdt = time.perf_counter() - t1
                 c_rays = cnt["rays_extend"] + cnt["rays_shadow"]
-                b_ray = oracle.algorithmic_bytes_per_extend_ray(cnt)
+                b_ray = oracle.algorithmic_bytes_per_ray(cnt)  # extend and shadow rays together, as the launches trace them
                 if True:
                     # the same sample once more on the GPU, outside the timed region: live parity
                     pc = p if (sw, sh) == (W, H) else device.PathTracingPass(ctx, sw, sh)
@@ -297,14 +302,19 @@ def main():
             pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % wl)
             if "roofline" in out and os.path.exists(pmc_file):
                 pmc = json.load(open(pmc_file))
-                names = ["intersect_fast_kernel", "intersect_kernel"] if wl == "casa_isect" else ["extend_fast_kernel", "extend_kernel"]
-                per = [pmc[n]["hbm_bytes_per_launch"] for n in names if n in pmc and "hbm_bytes_per_launch" in pmc[n]]
-                if per:
-                    out["roofline"]["traffic"] = float(sum(per))
+                names = ["intersect_fast_kernel", "intersect_kernel"] if wl == "casa_isect" else \
+                        ["path_trace_fast_kernel", "extend_fast_kernel", "extend_kernel", "shadow_fast_kernel", "shadow_kernel"]
+                have = [n for n in names if n in pmc and "FETCH_SIZE" in pmc[n] and "WRITE_SIZE" in pmc[n]]
+                if have:
+                    # total bytes of those kernels over the profiled run / number of main launches
+                    tot = sum((pmc[n]["FETCH_SIZE"]["total"] + pmc[n]["WRITE_SIZE"]["total"]) * 1024.0 for n in have)
+                    main = [n for n in have if n not in ("extend_kernel", "intersect_kernel")]
+                    n_launch = sum(pmc[n]["FETCH_SIZE"]["launches"] for n in main)
+                    out["roofline"]["traffic"] = tot / max(n_launch, 1)
                     out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_file)
                     out["roofline"]["algorithmic_bytes_per_launch"] = out["roofline"]["rays_per_launch"] * b_ray
             if prof:
-                out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms")}
+                out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "trace_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms")}
                 if "draws" in prof:
                     out["kernel_ms"]["over_draws"] = prof["draws"]
                     out["kernel_ms"]["one_draw_in_flight_ms_per_step"] = prof["serial_ms_per_step"]

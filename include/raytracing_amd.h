@@ -183,6 +183,9 @@ typedef struct pt_profile {
     double extend_ms, shadow_ms, shade_ms, other_ms; /* other = generate, shadow-apply, finalize */
     double intersect_ms;                             /* pt_pass_intersect launches            */
     uint64_t extend_launches, shadow_launches, shade_launches, other_launches, intersect_launches;
+    double trace_ms;         /* launches that trace the shadow rays of one vertex together with the
+                                extend rays of the next (ordered traversal, no analytic lights)     */
+    uint64_t trace_launches;
 } pt_profile;
 int pt_pass_set_profiling(pt_pass *pass, int enable);
 /* Waits for the stream, then reports the time accumulated since the last reset. */

@@ -55,7 +55,8 @@ class PtProfile(C.Structure):
     _fields_ = [("extend_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("other_ms", C.c_double), ("intersect_ms", C.c_double),
                 ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64), ("shade_launches", C.c_uint64),
-                ("other_launches", C.c_uint64), ("intersect_launches", C.c_uint64)]
+                ("other_launches", C.c_uint64), ("intersect_launches", C.c_uint64),
+                ("trace_ms", C.c_double), ("trace_launches", C.c_uint64)]
 
 
 # name -> (restype, argtypes); also the list the symbol-export test walks

@@ -292,7 +292,7 @@ TraceScene make_trace_scene(pt_pass *p, void *spill = nullptr) {
     return sc;
 }
 
-enum { K_EXTEND = 0, K_SHADOW = 1, K_SHADE = 2, K_OTHER = 3, K_INTERSECT = 4 };
+enum { K_EXTEND = 0, K_SHADOW = 1, K_SHADE = 2, K_OTHER = 3, K_INTERSECT = 4, K_TRACE = 5 };
 
 // Brackets one launch with two events when profiling is on.
 struct ScopedTimer {
@@ -332,6 +332,7 @@ void collect_profile(pt_pass *p) {
                 case K_SHADOW: p->prof.shadow_ms += ms; p->prof.shadow_launches++; break;
                 case K_SHADE: p->prof.shade_ms += ms; p->prof.shade_launches++; break;
                 case K_INTERSECT: p->prof.intersect_ms += ms; p->prof.intersect_launches++; break;
+                case K_TRACE: p->prof.trace_ms += ms; p->prof.trace_launches++; break;
                 default: p->prof.other_ms += ms; p->prof.other_launches++; break;
             }
         }
@@ -755,19 +756,23 @@ int pt_pass_draw(pt_pass *p) {
     unsigned *qa = static_cast<unsigned *>(L.queue_a.p), *qb = static_cast<unsigned *>(L.queue_b.p);
     unsigned *qs = static_cast<unsigned *>(L.queue_s.p);
     const unsigned *q_in = nullptr;  // vertex 0: every pixel, in pixel order
+    // In the ordered mode without analytic lights, the shadow rays of vertex d and the extend
+    // rays of vertex d+1 (both produced by shade(d)) share one launch.
+    const bool merged = ordered && n_shadow == 1;
+    auto extend = [&](int dep, const unsigned *q) {
+        ScopedTimer t(p, K_EXTEND);
+        if(ordered) {
+            launch_extend_fast(s, fsc, p->trace_blocks, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, qr,
+                               cnt + CNT_REDO + dep);
+            // near-ties in t: decided by the reference-order traversal
+            launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep);
+        } else {
+            launch_extend(s, sc, p->trace_blocks, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
+        }
+    };
+    extend(0, q_in);
     for(int dep = 0; dep <= P.MAX_DEPTH; dep++) {
         unsigned *q_out = (dep & 1) ? qb : qa;
-        {
-            ScopedTimer t(p, K_EXTEND);
-            if(ordered) {
-                launch_extend_fast(s, fsc, p->trace_blocks, q_in, cnt + CNT_QUEUE + dep, dp.rays, dp.hits,
-                                   cnt + CNT_NEXT + 2 * dep, qr, cnt + CNT_REDO + dep);
-                // near-ties in t: decided by the reference-order traversal
-                launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep);
-            } else {
-                launch_extend(s, sc, p->trace_blocks, q_in, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
-            }
-        }
         // shading the first vertex writes the last-write outputs: after the previous draw's
         if(dep == 0 && p->last_gbuf && p->last_gbuf != L.gbuf) HIP_TRY(hipStreamWaitEvent(s, p->last_gbuf, 0));
         {
@@ -779,14 +784,22 @@ int pt_pass_draw(pt_pass *p) {
             p->last_gbuf = L.gbuf;
         }
         if(dep < P.MAX_DEPTH) {
-            {
-                ScopedTimer t(p, K_SHADOW);
-                if(ordered && n_shadow == 1)
-                    launch_shadow_fast(s, fsc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, (int)npix,
-                                       cnt + CNT_NEXT + 2 * dep + 1);
-                else
-                    launch_shadow(s, sc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
-                                  cnt + CNT_NEXT + 2 * dep + 1);
+            if(merged) {
+                ScopedTimer t(p, K_TRACE);
+                launch_path_trace_fast(s, fsc, p->trace_blocks, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, dp.rays,
+                                       dp.hits, dp.shadow, (int)npix, cnt + CNT_NEXT + 2 * dep + 1, qr, cnt + CNT_REDO + dep + 1);
+                launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep + 1, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep + 1);
+            } else {
+                {
+                    ScopedTimer t(p, K_SHADOW);
+                    if(ordered && n_shadow == 1)
+                        launch_shadow_fast(s, fsc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, (int)npix,
+                                           cnt + CNT_NEXT + 2 * dep + 1);
+                    else
+                        launch_shadow(s, sc, p->trace_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
+                                      cnt + CNT_NEXT + 2 * dep + 1);
+                }
+                extend(dep + 1, q_out);
             }
             ScopedTimer t(p, K_OTHER);
             launch_shadow_apply(s, dp, qs, cnt + CNT_SHADOW + dep);

@@ -60,6 +60,9 @@ void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsign
 void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                         const PathRay *rays, ShadowEntry *shadow, int npix, unsigned *next_counter);
 
+void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue_e, const unsigned *count_e,
+                            const unsigned *queue_s, const unsigned *count_s, const PathRay *rays, PathHit *hits,
+                            ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo, unsigned *redo_count);
 void launch_generate(hipStream_t s, const DrawParams &dp);
 // shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to
 // queue_out and paths with pending light samples to shadow_queue.

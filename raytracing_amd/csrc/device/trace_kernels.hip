@@ -187,7 +187,49 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_fast_kernel(Fas
     trace_ordered(sc, src, sink, next_counter, *count, s_stack);
 }
 
+// ---- shadow rays of vertex d and extend rays of vertex d+1 in ONE launch ---------------------
+// Both are produced by shade(d) and neither reads what the other writes (shadow rays start at
+// the origin of the new ray, extend writes hits, shadow writes its own flags), so they share
+// one persistent launch: work item idx < n_extend is an extend ray, the rest are shadow rays.
+// Halves the number of trace launches per draw; late vertices carry few rays and each launch
+// costs at least the latency of its longest ray.
+struct PathSource {
+    ExtendSource e;
+    ShadowSource s;
+    unsigned n_extend;
+    __device__ bool load(unsigned idx, float o[3], float d[3], bool &any_hit) const {
+        return idx < n_extend ? e.load(idx, o, d, any_hit) : s.load(idx - n_extend, o, d, any_hit);
+    }
+};
+struct PathSink {
+    ExtendSinkFast e;
+    ShadowSink s;
+    unsigned n_extend;
+    __device__ void store(unsigned idx, const LaneHit &h, bool ambiguous) const {
+        if(idx < n_extend) e.store(idx, h, ambiguous);
+        else s.store(idx - n_extend, h);
+    }
+};
+
+__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel(
+    FastScene sc, const unsigned *queue_e, const unsigned *count_e, const unsigned *queue_s, const unsigned *count_s,
+    const PathRay *rays, PathHit *hits, ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo,
+    unsigned *redo_count) {
+    __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
+    const unsigned n_e = *count_e, n_s = *count_s;
+    PathSource src{ExtendSource{queue_e, rays}, ShadowSource{queue_s, rays, shadow, 1, npix}, n_e};
+    PathSink sink{ExtendSinkFast{queue_e, hits, redo, redo_count}, ShadowSink{queue_s, shadow, 1, npix}, n_e};
+    trace_ordered(sc, src, sink, next_counter, n_e + n_s, s_stack);
+}
+
 }  // namespace
+
+void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue_e, const unsigned *count_e,
+                            const unsigned *queue_s, const unsigned *count_s, const PathRay *rays, PathHit *hits,
+                            ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo, unsigned *redo_count) {
+    hipLaunchKernelGGL(path_trace_fast_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue_e, count_e, queue_s, count_s, rays,
+                       hits, shadow, npix, next_counter, redo, redo_count);
+}
 
 void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n,
                       const unsigned *redo, const unsigned *redo_count, pt_hit *hits, unsigned *next_counter) {

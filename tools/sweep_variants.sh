@@ -5,6 +5,6 @@ cd "$(dirname "$0")/.."
 fmt='import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], d["config"]["workload"][:12], round(d["value"],1), "Mrays/s", round(d["ms_per_step"],3), "ms/step")'
 for v in default "$@"; do
   if [ "$v" = default ]; then unset RAYTRACING_AMD_LIB; else export RAYTRACING_AMD_LIB=$PWD/raytracing_amd/libraytracing_amd.$v.so; fi
-  timeout -k 10 120 python3 -u bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-profile 2>/dev/null | python3 -c "$fmt" $v || exit 1
+  timeout -k 10 120 python3 -u bench.py --steps 64 --warmup 4 --no-cpu-baseline --no-profile 2>/dev/null | python3 -c "$fmt" $v || exit 1
   timeout -k 10 120 python3 -u bench.py --workload casa_isect --steps 6 --no-cpu-baseline --no-profile 2>/dev/null | python3 -c "$fmt" $v || exit 1
 done
