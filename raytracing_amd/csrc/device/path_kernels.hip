@@ -165,7 +165,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
             }
             history = history * (prev_fr * prev_cos / prev_pdf);  // :579
         }
-        if(dep >= P.MAX_DEPTH) continue;  // loop bound of :501
+        if(dep >= P.MAX_DEPTH && dep != 0) continue;  // loop bound of :501 (the first hit's outputs are due even at MAX_DEPTH 0)
 
         // ---- geometry of the hit (what intersect_triangle / intersect_meshBVH return, :239-248, :275-276)
         const float *tr = reinterpret_cast<const float *>(dp.tris + hit_tri);
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
             dp.o_normal[(size_t)i * 3 + 1] = normal.y;
             dp.o_normal[(size_t)i * 3 + 2] = normal.z;
             dp.o_inst[i] = (float)hit_inst;
+            if(dep >= P.MAX_DEPTH) continue;
         }
 
         // ---- :507-513

@@ -446,11 +446,12 @@ def _grid_mesh(pos, nu, nv, uv_scale=1.0):
     return np.ascontiguousarray(tri, np.float32)
 
 
-def synthetic_scene(n_tris=10_000_000, n_threads=0, seed=12345, dielectric_fraction=0.0):
+def synthetic_scene(n_tris=10_000_000, n_threads=0, seed=12345, dielectric_fraction=0.0, lights=0):
     """Procedural stand-in for the large configurations: a 4 x 4 tiling of displaced terrain
     patches and 48 displaced spheres resting above it, 64 meshes / 64 instances in all,
     about n_tris triangles, conductor materials with seeded roughness 0.05..0.8 (a
-    fraction may be rough dielectrics).  Deterministic for a given (n_tris, seed)."""
+    fraction may be rough dielectrics), optionally `lights` analytic lights (alternating
+    point and directional).  Deterministic for a given (n_tris, seed)."""
     rng = np.random.default_rng(seed)
     per_mesh = max(8, n_tris // 64)
     k = max(2, int(round(math.sqrt(per_mesh / 2.0))))
@@ -492,6 +493,11 @@ def synthetic_scene(n_tris=10_000_000, n_threads=0, seed=12345, dielectric_fract
         cy = float(height(cx, cz)) + scale * (0.9 + 1.5 * rng.random())
         rot = tuple(rng.random(3) * 360.0)
         b.add_instance(m, transform_matrix((cx, cy, cz), rot, (scale, scale, scale)), material())
+    for k in range(lights):
+        if k % 2 == 0:
+            b.add_point_light(transform_matrix((-10.0 + 9.0 * k, 14.0 + k, 6.0 - 5.0 * k)), (400.0, 350.0 + 20 * k, 300.0))
+        else:
+            b.add_directional_light(transform_matrix((0, 0, 0), (-50.0 - 7 * k, 30.0 * k, 0.0)), (2.0, 2.0, 1.6 + 0.1 * k))
     return b.finish(n_threads)
 
 
