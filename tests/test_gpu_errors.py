@@ -1,0 +1,123 @@
+"""Error behaviour of the boundary on a real device.  The reference has no error channel
+(SSBOBuffer.h and RenderPass.cpp print and carry on); this library returns a status and a
+message, and must refuse malformed scene buffers on the host instead of letting a kernel
+follow a bad index."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def fails(fn, *needles):
+    from raytracing_amd import _capi
+    with pytest.raises(_capi.PtError) as e:
+        fn()
+    msg = str(e.value)
+    for n in needles:
+        assert n in msg, msg
+    return msg
+
+
+def test_draw_preconditions(gpu_ctx, casa, small_sky):
+    from raytracing_amd import device, scene
+    w, h = 32, 18
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    fails(p.draw, "set_params")
+    prm = scene.make_params(w, h, scene.casa_camera(), small_sky)
+    p.set_params(prm)
+    fails(p.draw, "slot")                       # nothing bound
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    for slot, buf in enumerate(sb.buffers()):
+        p.bind(slot, buf)
+    fails(p.draw, "skybox")                     # sky texture not bound
+    p.bind_texture("skybox", sb.sky_tex)
+    fails(p.draw, "skybox_samplecache")
+    p.bind_texture("skybox_samplecache", sb.sky_cache_tex)
+    p.draw()                                    # complete now
+    bad = scene.make_params(w + 1, h, scene.casa_camera(), small_sky)
+    fails(lambda: p.set_params(bad), "SCREEN_W")
+    bad = scene.make_params(w, h, scene.casa_camera(), small_sky, max_depth=65)
+    fails(lambda: p.set_params(bad), "MAX_DEPTH")
+    bad = scene.make_params(w, h, scene.casa_camera(), small_sky, raster_first=True)
+    fails(lambda: p.set_params(bad), "RasterizaionFor1st")
+    bad = scene.make_params(w, h, scene.casa_camera(), small_sky, light_count=2)
+    p.set_params(bad)
+    fails(p.draw, "lightCount")                 # more lights than the bound buffer holds
+    fails(lambda: p.set_pipeline(0), "1..")
+    fails(lambda: p.set_traversal(2), "mode")
+    fails(lambda: p.bind_texture("depthGBufferTexture", sb.sky_tex), "unknown sampler")
+    p.destroy()
+    sb.release()
+
+
+def test_malformed_scene_buffers_are_refused(gpu_ctx, casa, small_sky):
+    from raytracing_amd import device, scene
+    w, h = 32, 18
+    prm = scene.make_params(w, h, scene.casa_camera(), small_sky)
+
+    def attempt(mutate, *needles):
+        import copy
+        sd = copy.copy(casa)
+        for name in ("mesh_nodes", "scene_nodes", "instances", "materials", "triangles"):
+            setattr(sd, name, getattr(casa, name).copy())
+        mutate(sd)
+        sb = device.SceneBuffers(gpu_ctx, sd, small_sky)
+        p = device.PathTracingPass(gpu_ctx, w, h)
+        p.bind_scene(sb)
+        p.set_params(prm)
+        try:
+            fails(p.draw, *needles)
+        finally:
+            p.destroy()
+            sb.release()
+
+    def child_out_of_range(sd):
+        sd.mesh_nodes["ls"][0] = len(sd.mesh_nodes) + 5
+    attempt(child_out_of_range, "rejected")
+
+    def triangle_out_of_range(sd):
+        leaf = np.nonzero(sd.mesh_nodes["tri"] >= 0)[0][0]
+        sd.mesh_nodes["tri"][leaf] = len(sd.triangles)
+    attempt(triangle_out_of_range, "rejected")
+
+    def cycle(sd):
+        inner = np.nonzero(sd.mesh_nodes["ls"] >= 0)[0]
+        sd.mesh_nodes["ls"][inner[3]] = 0       # back edge to a root
+    attempt(cycle, "rejected")
+
+    def bad_instance_mesh(sd):
+        sd.instances["meshIndex"][1] = 10_000_000
+    attempt(bad_instance_mesh, "rejected")
+
+    def bad_material_pointer(sd):
+        sd.instances["materialPtr"][0] = len(sd.materials) - 2
+    attempt(bad_material_pointer, "material")
+
+    def truncated_nodes(sd):
+        sd.mesh_nodes = sd.mesh_nodes[:-7].copy()
+    attempt(truncated_nodes, "rejected")
+
+
+def test_buffer_and_intersect_argument_checks(gpu_ctx, casa, small_sky):
+    from raytracing_amd import device, _capi
+    b = device.Buffer(gpu_ctx, np.arange(16, dtype=np.float32))
+    fails(lambda: b.copy_from_host(np.zeros(8, np.float32)), "size")
+    other = device.Buffer(gpu_ctx, nbytes=32)
+    fails(lambda: other.copy_from(b), "sizes differ")
+    out = np.zeros(32, np.float32)
+    assert _capi.lib.pt_buf_download(b.h, out.ctypes.data, 128) != 0   # more than the buffer holds
+    empty = device.Buffer(gpu_ctx, nbytes=0)                            # zero-length buffers are legal (no lights)
+    assert empty.nbytes == 0 and not empty.isempty()
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    p.bind_scene(sb)
+    rays = device.Buffer(gpu_ctx, np.zeros(6 * 10, np.float32))
+    hits = device.Buffer(gpu_ctx, nbytes=20 * 10)
+    fails(lambda: p.intersect(rays, 11, hits), "fewer than n rays")
+    small_hits = device.Buffer(gpu_ctx, nbytes=20 * 5)
+    fails(lambda: p.intersect(rays, 10, small_hits), "fewer than n records")
+    p.intersect(rays, 0, hits)                                          # n = 0 is a no-op
+    for x in (b, other, empty, rays, hits, small_hits):
+        x.release()
+    p.destroy()
+    sb.release()
