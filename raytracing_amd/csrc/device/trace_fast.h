@@ -57,18 +57,32 @@ struct FastScene {
 // the 1e-6 the comparisons are relaxed by.
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// relaxed slab test with a reciprocal direction; tn = entry distance (>= 0)
-__device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float hix, float hiy, float hiz, float ox,
-                                          float oy, float oz, float ix, float iy, float iz, float &tn, bool &clear) {
+// Slab distances with a reciprocal direction: entry (>= 0) and exit.
+__device__ __forceinline__ void slab_range(float lox, float loy, float loz, float hix, float hiy, float hiz, float ox,
+                                           float oy, float oz, float ix, float iy, float iz, float &tmi, float &tmx) {
     const float t1x = (lox - ox) * ix, t2x = (hix - ox) * ix;
     const float t1y = (loy - oy) * iy, t2y = (hiy - oy) * iy;
     const float t1z = (loz - oz) * iz, t2z = (hiz - oz) * iz;
-    float tmi = fmaxf(fmaxf(0.0f, fminf(t1x, t2x)), fmaxf(fminf(t1y, t2y), fminf(t1z, t2z)));
-    float tmx = fminf(fminf(RT_INF, fmaxf(t1x, t2x)), fminf(fmaxf(t1y, t2y), fmaxf(t1z, t2z)));
-    tn = tmi;
-    const float up = tmx * 1.000001f, dn = tmx * 0.999999f;
-    clear = dn >= tmi * 1.000001f && dn >= 0.001001f;
-    return up >= tmi * 0.999999f && up >= RT_RAY_MINDIS;
+    tmi = fmaxf(fmaxf(0.0f, fminf(t1x, t2x)), fmaxf(fminf(t1y, t2y), fminf(t1z, t2z)));
+    tmx = fminf(fminf(RT_INF, fmaxf(t1x, t2x)), fminf(fmaxf(t1y, t2y), fmaxf(t1z, t2z)));
+}
+// The reference passes a box when tmx >= tmi && tmx >= RAY_MINDIS (pathtracing.glsl:208-221).
+// relaxed_pass never fails a box the reference passes; clear_pass never passes one it fails.
+__device__ __forceinline__ bool relaxed_pass(float tmi, float tmx) {
+    const float up = tmx * 1.000002f;
+    return up >= tmi && up >= RT_RAY_MINDIS;
+}
+__device__ __forceinline__ bool clear_pass(float tmi, float tmx) {
+    const float dn = tmx * 0.999998f;
+    return dn >= tmi && dn >= 0.001001f;
+}
+// relaxed slab test; tn = entry distance (>= 0)
+__device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float hix, float hiy, float hiz, float ox,
+                                          float oy, float oz, float ix, float iy, float iz, float &tn, bool &clear) {
+    float tmx;
+    slab_range(lox, loy, loz, hix, hiy, hiz, ox, oy, oz, ix, iy, iz, tn, tmx);
+    clear = clear_pass(tn, tmx);
+    return relaxed_pass(tn, tmx);
 }
 
 // Source: bool load(unsigned idx, float o[3], float d[3], bool &any_hit)
@@ -156,14 +170,16 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
         for(;;) {
             // ---- take the next deferred entry that is still worth visiting, or finish the ray
             const float prune_t = best.t * 1.001f + 8.0f * abs_slack;
-            while(active && !have) {
+            // (one entry per step: a lane whose entry has fallen behind its closest hit
+            // tries again in the next step instead of making the wave loop here)
+            if(active && !have) {
                 if(sp > 0) {
                     --sp;
                     const uint2 e = sp < FAST_LDS_STACK ? s_stack[sp * FAST_BLOCK + tid]
                                                         : sc.spill[(size_t)(sp - FAST_LDS_STACK) * nthreads + gtid];
                     ref = e.x;
                     tn = __uint_as_float(e.y);
-                    have = !(tn > prune_t);  // it may have fallen behind the closest hit meanwhile
+                    have = !(tn > prune_t);
                 } else {
                     const bool ambiguous = !any_hit && best.tri >= 0 && second_t <= best.t * 1.0002f + 2.0f * abs_slack;
                     sink.store(ray_idx, best, ambiguous);
@@ -215,25 +231,27 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
             }
 
             if(is_inner) {
-                float t0, t1;
-                bool c0clear, c1clear;
-                bool p0 = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, c0clear);
-                bool p1 = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cix, ciy, ciz, t1, c1clear);
+                float t0, t1, x0, x1;
+                slab_range(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, x0);
+                slab_range(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cix, ciy, ciz, t1, x1);
+                bool p0 = relaxed_pass(t0, x0), p1 = relaxed_pass(t1, x1);
                 const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
                 const unsigned k0 = c0 >> 30, k1 = c1 >> 30;
                 // a triangle child has no box of its own: it inherits this node's fate, which
                 // the exact parent-box test at the leaf settles; order it by this node's entry
                 if(k0 == REF_TRIANGLE) { p0 = true; t0 = tn; }
                 if(k1 == REF_TRIANGLE) { p1 = true; t1 = tn; }
-                // an instance child: its box is the scene leaf box, whose EXACT test decides
-                // whether anything inside the instance is a candidate
-                if(k0 == REF_INSTANCE && p0 && !c0clear) {
-                    float te;
-                    p0 = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cdx, cdy, cdz, te);
-                }
-                if(k1 == REF_INSTANCE && p1 && !c1clear) {
-                    float te;
-                    p1 = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cdx, cdy, cdz, te);
+                // an instance child (scene level only): its box is the scene leaf box, whose
+                // EXACT test decides whether anything inside the instance is a candidate
+                if(kind == REF_SCENE_INNER) {
+                    if(k0 == REF_INSTANCE && p0 && !clear_pass(t0, x0)) {
+                        float te;
+                        p0 = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cdx, cdy, cdz, te);
+                    }
+                    if(k1 == REF_INSTANCE && p1 && !clear_pass(t1, x1)) {
+                        float te;
+                        p1 = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cdx, cdy, cdz, te);
+                    }
                 }
                 p0 = p0 && t0 <= prune_t;
                 p1 = p1 && t1 <= prune_t;
