@@ -219,9 +219,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                                                              : reinterpret_cast<const char *>(sc.inst + idx);
                 const float4 *rp = reinterpret_cast<const float4 *>(base);
                 q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3];
-            } else {
-                q0 = q1 = q2 = q3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
+            }  // (lanes that are not served leave q0..q3 unset and never read them)
             // scene-level entries are met with the world ray
             if(go && kind >= REF_SCENE_INNER && in_mesh) {
                 cox = wox; coy = woy; coz = woz;

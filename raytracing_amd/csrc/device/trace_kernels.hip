@@ -8,12 +8,12 @@
 namespace rta {
 namespace {
 
-// Occupancy hint for the ordered kernels (waves per SIMD the register allocator aims for).
-#ifdef RT_FAST_WAVES
-#define RT_FAST_OCC __attribute__((amdgpu_waves_per_eu(RT_FAST_WAVES, RT_FAST_WAVES)))
-#else
-#define RT_FAST_OCC
+// The ordered kernels must fit 4 waves per SIMD (128 VGPRs); one register more costs a quarter
+// of the occupancy.
+#ifndef RT_FAST_WAVES
+#define RT_FAST_WAVES 4
 #endif
+#define RT_FAST_OCC __attribute__((amdgpu_waves_per_eu(RT_FAST_WAVES)))
 
 // ---- stand-alone closest hit -----------------------------------------------------------
 // `redo`, when given, lists the ray indices to trace (the ordered kernel's undecided rays).
