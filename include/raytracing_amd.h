@@ -154,7 +154,12 @@ typedef struct pt_stats {
     uint64_t rays_shadow;    /* occlusion queries: sky NEE + light shadow rays    */
     uint64_t draws;
     uint64_t rays_retraced;  /* closest-hit queries the ordered traversal handed to the reference-order one */
-    uint64_t reserved[3];
+    /* How often the pass re-laid out its traversal arrays since it was created: the mesh
+     * level follows slots 2 and 4, the scene level slots 3 and 5 (re-uploaded by the reference
+     * every frame while instances move); not reset. */
+    uint64_t mesh_level_builds, scene_level_builds;
+    uint64_t debug[3];       /* step counters of RT_TRACE_STATS builds, else 0 */
+    uint64_t reserved[2];
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 

@@ -47,7 +47,8 @@ class PtParams(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64), ("rays_extend", C.c_uint64), ("rays_shadow", C.c_uint64),
-        ("draws", C.c_uint64), ("rays_retraced", C.c_uint64), ("reserved", C.c_uint64 * 3),
+        ("draws", C.c_uint64), ("rays_retraced", C.c_uint64), ("mesh_level_builds", C.c_uint64),
+                ("scene_level_builds", C.c_uint64), ("debug", C.c_uint64 * 3), ("reserved", C.c_uint64 * 2),
     ]
 
 

@@ -110,8 +110,13 @@ struct pt_pass {
     pt_params params;
     bool have_params = false;
     // derived scene
-    bool accel_valid = false;
-    AccelHost accel_info;  // header + sizes (vectors are cleared after upload)
+    // Two levels, rebuilt separately: the mesh level follows the triangle and mesh-BVH slots,
+    // the (small) scene level the instance and scene-BVH slots, which the reference re-uploads
+    // every frame while instances move (Config::DynamicBVH, main.cpp).
+    bool mesh_level_valid = false, scene_level_valid = false;
+    AccelMeshLevel mesh_level;    // device arrays are cleared after upload; the two lookup tables stay
+    AccelSceneLevel scene_level;  // header + max_stack (vectors are cleared after upload)
+    uint64_t mesh_level_builds = 0, scene_level_builds = 0;
     DeviceArray d_mesh_nodes, d_scene_nodes, d_tri_pos, d_tri_leaf, d_inst, d_spill, d_tex_table;
     DeviceArray d_redo_isect;  // redo list of the ordered intersect
     int traversal_mode = 0;               // 0 ordered + exact fallback, 1 reference order only
@@ -149,17 +154,20 @@ struct pt_pass {
 
 namespace {
 
-int download_shadow(pt_buf *b, std::vector<uint8_t> &out) {
+// The bytes of a buffer on the host: its upload shadow when there is one (no copy), else a
+// download into `tmp`.
+int host_view(pt_buf *b, std::vector<uint8_t> &tmp, const uint8_t **out) {
     if(b->shadow_valid) {
-        out = b->shadow;
+        *out = b->shadow.data();
         return PT_OK;
     }
-    out.resize(b->bytes);
+    tmp.resize(b->bytes);
     if(b->bytes) {
         JOIN_TRY(b->ctx);
         HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-        HIP_TRY(hipMemcpy(out.data(), b->dptr, b->bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tmp.data(), b->dptr, b->bytes, hipMemcpyDeviceToHost));
     }
+    *out = tmp.data();
     return PT_OK;
 }
 
@@ -192,46 +200,66 @@ int prepare_scene(pt_pass *p) {
         if(!p->slots[s] || p->slots[s]->bytes == 0)
             return fail(PT_ERR_STATE, "scene slot " + std::to_string(s) + " is not bound or empty");
 
-    const bool geo_changed = !p->accel_valid || slot_changed(p, PT_SLOT_TRIANGLE) || slot_changed(p, PT_SLOT_INSTANCE_INFO) ||
-                             slot_changed(p, PT_SLOT_MESH_BVH) || slot_changed(p, PT_SLOT_SCENE_BVH);
+    const bool mesh_changed = !p->mesh_level_valid || slot_changed(p, PT_SLOT_TRIANGLE) || slot_changed(p, PT_SLOT_MESH_BVH);
+    const bool scene_changed = mesh_changed || !p->scene_level_valid || slot_changed(p, PT_SLOT_INSTANCE_INFO) ||
+                               slot_changed(p, PT_SLOT_SCENE_BVH);
     const bool mat_changed = slot_changed(p, PT_SLOT_MATERIAL);
-    if(geo_changed || mat_changed) {
-        std::vector<uint8_t> tris, inst, mesh, scene, mats;
+    if(scene_changed || mat_changed) {
+        std::vector<uint8_t> t_inst, t_mats, t_tris, t_mesh, t_scene;
+        const uint8_t *inst = nullptr, *mats = nullptr, *tris = nullptr, *mesh = nullptr, *scene = nullptr;
         int rc;
-        if((rc = download_shadow(p->slots[PT_SLOT_INSTANCE_INFO], inst))) return rc;
-        if((rc = download_shadow(p->slots[PT_SLOT_MATERIAL], mats))) return rc;
-        if(inst.size() % sizeof(InstanceInfo)) return fail(PT_ERR_INVALID, "instance buffer size is not a multiple of 112");
-        if(mats.size() % 4) return fail(PT_ERR_INVALID, "material buffer size is not a multiple of 4");
-        const size_t n_inst = inst.size() / sizeof(InstanceInfo), n_mat = mats.size() / 4;
-        const InstanceInfo *ii = reinterpret_cast<const InstanceInfo *>(inst.data());
-        const float *mf = reinterpret_cast<const float *>(mats.data());
+        pt_buf *b_inst = p->slots[PT_SLOT_INSTANCE_INFO], *b_mats = p->slots[PT_SLOT_MATERIAL], *b_tris = p->slots[PT_SLOT_TRIANGLE],
+               *b_mesh = p->slots[PT_SLOT_MESH_BVH], *b_scene = p->slots[PT_SLOT_SCENE_BVH];
+        if((rc = host_view(b_inst, t_inst, &inst))) return rc;
+        if((rc = host_view(b_mats, t_mats, &mats))) return rc;
+        if(b_inst->bytes % sizeof(InstanceInfo)) return fail(PT_ERR_INVALID, "instance buffer size is not a multiple of 112");
+        if(b_mats->bytes % 4) return fail(PT_ERR_INVALID, "material buffer size is not a multiple of 4");
+        const size_t n_inst = b_inst->bytes / sizeof(InstanceInfo), n_mat = b_mats->bytes / 4;
+        const InstanceInfo *ii = reinterpret_cast<const InstanceInfo *>(inst);
+        const float *mf = reinterpret_cast<const float *>(mats);
         for(size_t i = 0; i < n_inst; i++) {
             const int mp = ii[i].materialPtr;
             if(mp < 0 || (size_t)mp + 7 > n_mat) return fail(PT_ERR_INVALID, "instance " + std::to_string(i) + ": material pointer outside the material buffer");
             if((int)(mf[mp] + 0.5f) == 2 && (size_t)mp + 8 > n_mat) return fail(PT_ERR_INVALID, "instance " + std::to_string(i) + ": dielectric record is truncated");
         }
         p->n_material_floats = n_mat;
-        if(geo_changed) {
-            if((rc = download_shadow(p->slots[PT_SLOT_TRIANGLE], tris))) return rc;
-            if((rc = download_shadow(p->slots[PT_SLOT_MESH_BVH], mesh))) return rc;
-            if((rc = download_shadow(p->slots[PT_SLOT_SCENE_BVH], scene))) return rc;
-            if(tris.size() % sizeof(TriangleRec) || mesh.size() % sizeof(BVHNodeInfo) || scene.size() % sizeof(BVHNodeInfo))
+        if(scene_changed) {
+            if((rc = host_view(b_mesh, t_mesh, &mesh))) return rc;
+            if((rc = host_view(b_scene, t_scene, &scene))) return rc;
+            if(b_tris->bytes % sizeof(TriangleRec) || b_mesh->bytes % sizeof(BVHNodeInfo) || b_scene->bytes % sizeof(BVHNodeInfo))
                 return fail(PT_ERR_INVALID, "triangle / BVH buffer sizes are not multiples of 96 / 48 bytes");
-            AccelHost ah;
+            const BVHNodeInfo *mesh_n = reinterpret_cast<const BVHNodeInfo *>(mesh);
+            const size_t n_mesh_nodes = b_mesh->bytes / sizeof(BVHNodeInfo);
             std::string err;
-            if(!build_accel(reinterpret_cast<const BVHNodeInfo *>(mesh.data()), mesh.size() / sizeof(BVHNodeInfo),
-                            reinterpret_cast<const BVHNodeInfo *>(scene.data()), scene.size() / sizeof(BVHNodeInfo),
-                            reinterpret_cast<const TriangleRec *>(tris.data()), tris.size() / sizeof(TriangleRec), ii,
-                            n_inst, ah, err))
+            if(mesh_changed) {
+                if((rc = host_view(b_tris, t_tris, &tris))) return rc;
+                p->mesh_level_valid = false;
+                p->scene_level_valid = false;
+                AccelMeshLevel &ml = p->mesh_level;
+                if(!build_accel_mesh_level(mesh_n, n_mesh_nodes, reinterpret_cast<const TriangleRec *>(tris), b_tris->bytes / sizeof(TriangleRec), ml, err))
+                    return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
+                if((rc = upload_array(ctx, p->d_mesh_nodes, ml.mesh_nodes.data(), ml.mesh_nodes.size() * sizeof(TNode)))) return rc;
+                if((rc = upload_array(ctx, p->d_tri_pos, ml.tri_pos.data(), ml.tri_pos.size() * sizeof(TriPos)))) return rc;
+                if((rc = upload_array(ctx, p->d_tri_leaf, ml.tri_leaf.data(), ml.tri_leaf.size() * sizeof(TLeaf)))) return rc;
+                std::vector<TNode>().swap(ml.mesh_nodes);
+                std::vector<TriPos>().swap(ml.tri_pos);
+                std::vector<TLeaf>().swap(ml.tri_leaf);
+                p->mesh_level_valid = true;
+                p->mesh_level_builds++;
+                slot_mark(p, PT_SLOT_TRIANGLE);
+                slot_mark(p, PT_SLOT_MESH_BVH);
+            }
+            AccelSceneLevel sl;
+            if(!build_accel_scene_level(mesh_n, n_mesh_nodes, p->mesh_level, reinterpret_cast<const BVHNodeInfo *>(scene),
+                                        b_scene->bytes / sizeof(BVHNodeInfo), ii, n_inst, sl, err)) {
+                p->scene_level_valid = false;
                 return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
-            if((rc = upload_array(ctx, p->d_mesh_nodes, ah.mesh_nodes.data(), ah.mesh_nodes.size() * sizeof(TNode)))) return rc;
-            if((rc = upload_array(ctx, p->d_scene_nodes, ah.scene_nodes.data(), ah.scene_nodes.size() * sizeof(TNode)))) return rc;
-            if((rc = upload_array(ctx, p->d_tri_pos, ah.tri_pos.data(), ah.tri_pos.size() * sizeof(TriPos)))) return rc;
-            if((rc = upload_array(ctx, p->d_tri_leaf, ah.tri_leaf.data(), ah.tri_leaf.size() * sizeof(TLeaf)))) return rc;
-            if((rc = upload_array(ctx, p->d_inst, ah.instances.data(), ah.instances.size() * sizeof(InstAccel)))) return rc;
-            p->accel_info.header = ah.header;
-            p->accel_info.max_stack = ah.max_stack;
-            int need = ah.max_stack + 2 - (LDS_STACK < FAST_LDS_STACK ? LDS_STACK : FAST_LDS_STACK);
+            }
+            if((rc = upload_array(ctx, p->d_scene_nodes, sl.scene_nodes.data(), sl.scene_nodes.size() * sizeof(TNode)))) return rc;
+            if((rc = upload_array(ctx, p->d_inst, sl.instances.data(), sl.instances.size() * sizeof(InstAccel)))) return rc;
+            p->scene_level.header = sl.header;
+            p->scene_level.max_stack = sl.max_stack;
+            int need = sl.max_stack + 2 - (LDS_STACK < FAST_LDS_STACK ? LDS_STACK : FAST_LDS_STACK);
             if(need < 0) need = 0;
             if(need > p->spill_depth || !p->d_spill.p) {
                 JOIN_TRY(ctx);
@@ -240,9 +268,8 @@ int prepare_scene(pt_pass *p) {
                 const size_t nthreads = (size_t)p->trace_blocks * TRACE_BLOCK;
                 if((rc = p->d_spill.ensure(nthreads * (size_t)p->spill_depth * sizeof(uint2)))) return rc;
             }
-            p->accel_valid = true;
-            slot_mark(p, PT_SLOT_TRIANGLE);
-            slot_mark(p, PT_SLOT_MESH_BVH);
+            p->scene_level_valid = true;
+            p->scene_level_builds++;
             slot_mark(p, PT_SLOT_SCENE_BVH);
         }
         slot_mark(p, PT_SLOT_INSTANCE_INFO);
@@ -252,12 +279,13 @@ int prepare_scene(pt_pass *p) {
         std::vector<TexDesc> table;
         pt_buf *hb = p->slots[PT_SLOT_TEXTURE_HANDLES];
         if(hb && hb->bytes) {
-            std::vector<uint8_t> raw;
-            int rc = download_shadow(hb, raw);
+            std::vector<uint8_t> tmp;
+            const uint8_t *raw = nullptr;
+            int rc = host_view(hb, tmp, &raw);
             if(rc) return rc;
-            if(raw.size() % 8) return fail(PT_ERR_INVALID, "texture handle buffer size is not a multiple of 8");
-            const uint64_t *h = reinterpret_cast<const uint64_t *>(raw.data());
-            for(size_t k = 0; k < raw.size() / 8; k++) {
+            if(hb->bytes % 8) return fail(PT_ERR_INVALID, "texture handle buffer size is not a multiple of 8");
+            const uint64_t *h = reinterpret_cast<const uint64_t *>(raw);
+            for(size_t k = 0; k < hb->bytes / 8; k++) {
                 auto it = ctx->textures.find(h[k]);
                 if(it == ctx->textures.end()) return fail(PT_ERR_INVALID, "texture handle " + std::to_string(k) + " does not name a live texture of this context");
                 TexDesc d;
@@ -285,7 +313,7 @@ TraceScene make_trace_scene(pt_pass *p, void *spill = nullptr) {
     sc.scene_nodes = static_cast<const TNode *>(p->d_scene_nodes.p);
     sc.tri_pos = static_cast<const TriPos *>(p->d_tri_pos.p);
     sc.inst = static_cast<const InstAccel *>(p->d_inst.p);
-    sc.hdr = p->accel_info.header;
+    sc.hdr = p->scene_level.header;
     sc.spill = static_cast<uint2 *>(spill ? spill : p->d_spill.p);
     sc.spill_depth = p->spill_depth;
     sc.error_flag = static_cast<unsigned *>(p->d_err.p);
@@ -348,7 +376,7 @@ FastScene make_fast_scene(pt_pass *p, void *spill = nullptr) {
     sc.scene_nodes = static_cast<const TNode *>(p->d_scene_nodes.p);
     sc.tri_leaf = static_cast<const TLeaf *>(p->d_tri_leaf.p);
     sc.inst = static_cast<const InstAccel *>(p->d_inst.p);
-    sc.hdr = p->accel_info.header;
+    sc.hdr = p->scene_level.header;
     sc.spill = static_cast<uint2 *>(spill ? spill : p->d_spill.p);
     sc.spill_depth = p->spill_depth;
     sc.error_flag = static_cast<unsigned *>(p->d_err.p);
@@ -864,7 +892,9 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     out->rays_shadow = raw[2];
     out->draws = raw[3];
     out->rays_retraced = raw[4];
-    HIP_TRY(hipMemcpy(out->reserved, static_cast<char *>(pass->d_err.p) + 16, 24, hipMemcpyDeviceToHost));
+    out->mesh_level_builds = pass->mesh_level_builds;
+    out->scene_level_builds = pass->scene_level_builds;
+    HIP_TRY(hipMemcpy(out->debug, static_cast<char *>(pass->d_err.p) + 16, 24, hipMemcpyDeviceToHost));
     if(reset) {
         HIP_TRY(hipMemsetAsync(pass->d_stats.p, 0, 64, pass->ctx->stream));
         HIP_TRY(hipMemsetAsync(static_cast<char *>(pass->d_err.p) + 16, 0, 32, pass->ctx->stream));

@@ -28,19 +28,19 @@ bool check_children(const BVHNodeInfo *nodes, size_t n, size_t i, const char *wh
 
 }  // namespace
 
-bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo *scene, size_t n_scene_nodes,
-                 const TriangleRec *tris, size_t n_tris, const InstanceInfo *inst, size_t n_inst, AccelHost &out,
-                 std::string &err) {
-    if(n_mesh_nodes == 0 || n_scene_nodes == 0 || n_tris == 0 || n_inst == 0) {
-        err = "scene buffers must not be empty (mesh BVH, scene BVH, triangles, instances)";
+bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const TriangleRec *tris, size_t n_tris,
+                            AccelMeshLevel &out, std::string &err) {
+    if(n_mesh_nodes == 0 || n_tris == 0) {
+        err = "scene buffers must not be empty (mesh BVH, triangles)";
         return false;
     }
-    if(n_mesh_nodes >= REF_INDEX_MASK || n_tris >= REF_INDEX_MASK || n_inst >= REF_INDEX_MASK) {
+    if(n_mesh_nodes >= REF_INDEX_MASK || n_tris >= REF_INDEX_MASK) {
         err = "scene too large for 30-bit references";
         return false;
     }
-    // ---- mesh level
-    std::vector<uint32_t> inner_of(n_mesh_nodes, 0);
+    out.n_tris = n_tris;
+    std::vector<uint32_t> &inner_of = out.inner_of;
+    inner_of.assign(n_mesh_nodes, 0);
     uint32_t n_inner = 0;
     for(size_t i = 0; i < n_mesh_nodes; i++) {
         if(mesh[i].triangleIndex >= 0) {
@@ -59,7 +59,7 @@ bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo
     };
     out.mesh_nodes.assign(std::max<size_t>(n_inner, 1), TNode());
     memset(out.mesh_nodes.data(), 0, out.mesh_nodes.size() * sizeof(TNode));
-    std::vector<int> height(n_mesh_nodes, 1);
+    out.height.assign(n_mesh_nodes, 1);
     for(size_t ii = n_mesh_nodes; ii-- > 0;) {
         const BVHNodeInfo &p = mesh[ii];
         if(p.triangleIndex >= 0) continue;
@@ -68,7 +68,8 @@ bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo
         set_box(t.lo1, t.hi1, mesh[p.rsIndex]);
         t.c0 = mesh_ref(p.lsIndex);
         t.c1 = mesh_ref(p.rsIndex);
-        height[ii] = std::max(height[p.lsIndex], height[p.rsIndex]) + 1;
+        const int h = std::max<int>(out.height[p.lsIndex], out.height[p.rsIndex]) + 1;
+        out.height[ii] = (uint8_t)std::min(h, 255);
     }
     // ---- triangles
     out.tri_pos.resize(n_tris);
@@ -84,34 +85,54 @@ bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo
     }
     // ---- ordered-traversal leaves: triangle + exact box of the reference parent node
     out.tri_leaf.resize(n_tris);
-    {
-        const float inf = std::numeric_limits<float>::infinity();
-        for(size_t i = 0; i < n_tris; i++) {
-            TLeaf &l = out.tri_leaf[i];
-            const TriPos &t = out.tri_pos[i];
-            for(int k = 0; k < 3; k++) {
-                l.parent_lo[k] = -inf;
-                l.parent_hi[k] = inf;
-                l.v0[k] = t.v0[k];
-                l.e1[k] = t.e1[k];
-                l.e2[k] = t.e2[k];
-            }
-            l.pad = 0.0f;
+    const float inf = std::numeric_limits<float>::infinity();
+    for(size_t i = 0; i < n_tris; i++) {
+        TLeaf &l = out.tri_leaf[i];
+        const TriPos &t = out.tri_pos[i];
+        for(int k = 0; k < 3; k++) {
+            l.parent_lo[k] = -inf;
+            l.parent_hi[k] = inf;
+            l.v0[k] = t.v0[k];
+            l.e1[k] = t.e1[k];
+            l.e2[k] = t.e2[k];
         }
-        for(size_t ii = 0; ii < n_mesh_nodes; ii++) {
-            const BVHNodeInfo &p = mesh[ii];
-            if(p.triangleIndex >= 0) continue;
-            const int32_t kids[2] = {p.lsIndex, p.rsIndex};
-            for(int32_t c : kids)
-                if(mesh[c].triangleIndex >= 0) {
-                    TLeaf &l = out.tri_leaf[mesh[c].triangleIndex];
-                    for(int k = 0; k < 3; k++) {
-                        l.parent_lo[k] = p.aa[k];
-                        l.parent_hi[k] = p.bb[k];
-                    }
-                }
-        }
+        l.pad = 0.0f;
     }
+    for(size_t ii = 0; ii < n_mesh_nodes; ii++) {
+        const BVHNodeInfo &p = mesh[ii];
+        if(p.triangleIndex >= 0) continue;
+        const int32_t kids[2] = {p.lsIndex, p.rsIndex};
+        for(int32_t c : kids)
+            if(mesh[c].triangleIndex >= 0) {
+                TLeaf &l = out.tri_leaf[mesh[c].triangleIndex];
+                for(int k = 0; k < 3; k++) {
+                    l.parent_lo[k] = p.aa[k];
+                    l.parent_hi[k] = p.bb[k];
+                }
+            }
+    }
+    return true;
+}
+
+bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const AccelMeshLevel &ml, const BVHNodeInfo *scene,
+                             size_t n_scene_nodes, const InstanceInfo *inst, size_t n_inst, AccelSceneLevel &out,
+                             std::string &err) {
+    if(n_scene_nodes == 0 || n_inst == 0) {
+        err = "scene buffers must not be empty (scene BVH, instances)";
+        return false;
+    }
+    if(n_inst >= REF_INDEX_MASK || n_scene_nodes >= REF_INDEX_MASK) {
+        err = "scene too large for 30-bit references";
+        return false;
+    }
+    if(ml.inner_of.size() != n_mesh_nodes) {
+        err = "mesh level was built for another mesh BVH";
+        return false;
+    }
+    auto mesh_ref = [&](int32_t c) {
+        return mesh[c].triangleIndex >= 0 ? make_ref(REF_TRIANGLE, (uint32_t)mesh[c].triangleIndex)
+                                          : make_ref(REF_MESH_INNER, ml.inner_of[c]);
+    };
     // ---- instances
     out.instances.resize(n_inst);
     int max_mesh_height = 1;
@@ -138,7 +159,7 @@ bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo
         }
         memset(a.pad0, 0, sizeof a.pad0);
         memset(a.pad1, 0, sizeof a.pad1);
-        max_mesh_height = std::max(max_mesh_height, height[s.meshIndex]);
+        max_mesh_height = std::max<int>(max_mesh_height, ml.height[s.meshIndex]);
     }
     // ---- scene level
     std::vector<uint32_t> sinner_of(n_scene_nodes, 0);

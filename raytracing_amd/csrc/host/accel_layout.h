@@ -10,19 +10,31 @@
 
 namespace rta {
 
-struct AccelHost {
+// Mesh level: depends on the triangle and mesh-BVH buffers only.
+struct AccelMeshLevel {
     std::vector<TNode> mesh_nodes;
-    std::vector<TNode> scene_nodes;
     std::vector<TriPos> tri_pos;
-    std::vector<TLeaf> tri_leaf;   // same index as tri_pos
+    std::vector<TLeaf> tri_leaf;        // same index as tri_pos
+    // kept on the host for the scene level (instances name their mesh root by node index)
+    std::vector<uint32_t> inner_of;     // reference node index -> index in mesh_nodes (inner nodes)
+    std::vector<uint8_t> height;        // height of the subtree under each reference node, capped at 255
+    size_t n_tris = 0;
+};
+
+// Scene level: depends on the instance and scene-BVH buffers (and the mesh roots' boxes).
+// Small; rebuilt whenever instances move (the reference does that every frame, DynamicBVH).
+struct AccelSceneLevel {
+    std::vector<TNode> scene_nodes;
     std::vector<InstAccel> instances;
     SceneHeader header;
     int max_stack = 0;  // upper bound of deferred entries one ray can hold (scene + mesh height)
 };
 
-// Returns false and sets err when the buffers are inconsistent.
-bool build_accel(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const BVHNodeInfo *scene, size_t n_scene_nodes,
-                 const TriangleRec *tris, size_t n_tris, const InstanceInfo *inst, size_t n_inst, AccelHost &out,
-                 std::string &err);
+// Both return false and set err when the buffers are inconsistent.
+bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const TriangleRec *tris, size_t n_tris,
+                            AccelMeshLevel &out, std::string &err);
+bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const AccelMeshLevel &ml, const BVHNodeInfo *scene,
+                             size_t n_scene_nodes, const InstanceInfo *inst, size_t n_inst, AccelSceneLevel &out,
+                             std::string &err);
 
 }  // namespace rta

@@ -177,6 +177,7 @@ class SceneBuilder:
                                       _f32p(sd.l2w), _i32p(mesh_index), _i32p(material_ptr), n_inst,
                                       sd.instances.ctypes.data, sd.scene_nodes.ctypes.data, _i32p(stats)))
         sd.bvh_siz, sd.bvh_depth = int(stats[0]), int(stats[1])
+        sd.mesh_index, sd.material_ptr = mesh_index, material_ptr
         sd.lights = np.zeros(len(self._lights), LIGHT_DTYPE)
         for k, (t, p, e) in enumerate(self._lights):
             sd.lights[k] = (t, p, e, 0.0)
@@ -499,6 +500,24 @@ def synthetic_scene(n_tris=10_000_000, n_threads=0, seed=12345, dielectric_fract
         else:
             b.add_directional_light(transform_matrix((0, 0, 0), (-50.0 - 7 * k, 30.0 * k, 0.0)), (2.0, 2.0, 1.6 + 0.1 * k))
     return b.finish(n_threads)
+
+
+def rebuild_scene_level(sd, l2w):
+    """ResourceManager::reload_scene (src/ResourceManager.cpp:200-224) after instances moved:
+    new instance records and scene BVH for local-to-world matrices `l2w` (n_inst x 16), meshes
+    untouched.  Returns a shallow copy of `sd` with instances / scene_nodes / l2w replaced."""
+    import copy
+    out = copy.copy(sd)
+    n_inst = len(sd.instances)
+    out.l2w = np.ascontiguousarray(l2w, np.float32).reshape(n_inst, 16)
+    out.instances = np.zeros(n_inst, INSTANCE_DTYPE)
+    out.scene_nodes = np.zeros(2 * n_inst - 1, NODE_DTYPE)
+    stats = np.zeros(2, np.int32)
+    check(lib.pt_host_build_scene(_f32p(sd.mesh_root_box), _i32p(sd.mesh_siz), _i32p(sd.mesh_depth), len(sd.mesh_siz),
+                                  _f32p(out.l2w), _i32p(sd.mesh_index), _i32p(sd.material_ptr), n_inst,
+                                  out.instances.ctypes.data, out.scene_nodes.ctypes.data, _i32p(stats)))
+    out.bvh_siz, out.bvh_depth = int(stats[0]), int(stats[1])
+    return out
 
 
 def synthetic_camera():

@@ -105,3 +105,34 @@ def test_scene_rebinding_between_draws(mixed_scene, casa, small_sky, oracle_mod,
     ref, _ = oracle_mod.OracleScene(casa, small_sky).render(prm2)
     check(out, ref)
     p.destroy(); sb1.release(); sb2.release()
+
+
+def test_moving_instances_rebuilds_only_the_scene_level(mixed_scene, small_sky, oracle_mod, gpu_ctx):
+    """The reference re-uploads instanceInfoSSBO and sceneBVHSSBO every frame while instances
+    move (DynamicBVH): the pass re-lays out its scene level only, and renders the new frame."""
+    from raytracing_amd import device, scene
+    w, h = 96, 54
+    sb = device.SceneBuffers(gpu_ctx, mixed_scene, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    prm = scene.make_params(w, h, scene.synthetic_camera(), small_sky, max_depth=3, light_count=len(mixed_scene.lights))
+    p.set_params(prm)
+    p.draw()
+    sd = mixed_scene
+    for frame in range(1, 4):
+        l2w = sd.l2w.copy().reshape(-1, 4, 4)
+        l2w[20:30, 3, 1] += 1.5 * frame          # lift ten spheres (translation sits in the last column = row 3 here)
+        l2w[17, 3, 0] -= 2.0 * frame
+        moved = scene.rebuild_scene_level(mixed_scene, l2w.reshape(-1, 16))
+        sb.instanceInfoSSBO.copy_from_host(moved.instances)
+        sb.sceneBVHSSBO.copy_from_host(moved.scene_nodes)
+        p.set_params(prm)
+        p.draw()
+        ref, _ = oracle_mod.OracleScene(moved, small_sky).render(prm)
+        check(p.download(), ref)
+    st = p.stats()
+    assert st["mesh_level_builds"] == 1 and st["scene_level_builds"] == 4
+    first, _ = oracle_mod.OracleScene(mixed_scene, small_sky).render(prm)
+    assert not np.array_equal(first["depth"], ref["depth"])   # the scene did change
+    p.destroy()
+    sb.release()
