@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tris", type=int, default=10_000_000, help="synth_pt: triangle count")
+    ap.add_argument("--dielectric", type=float, default=0.0, help="synth_pt: fraction of rough dielectric instances")
+    ap.add_argument("--textures", type=int, default=0, help="synth_pt: number of procedural RGBA8 albedo maps")
+    ap.add_argument("--texture-size", type=int, default=4096)
     ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
     ap.add_argument("--pipeline", type=int, default=6, help="draws in flight on the device (pt_pass_set_pipeline)")
     ap.add_argument("--rehearse", action="store_true",
@@ -93,8 +96,16 @@ def main():
     warmup = args.warmup if args.warmup is not None else (4 if wl != "casa_isect" else 2)
 
     t_setup = time.time()
+    # large synthetic scenes take minutes to generate and build: say so now and then
+    import threading
+    setup_done = threading.Event()
+
+    def heartbeat():
+        while not setup_done.wait(30.0):
+            print("[bench] setting up the scene, %.0f s" % (time.time() - t_setup), file=sys.stderr, flush=True)
+    threading.Thread(target=heartbeat, daemon=True).start()
     if wl == "synth_pt":
-        sd = scene.synthetic_scene(args.tris)
+        sd = scene.synthetic_scene(args.tris, dielectric_fraction=args.dielectric, textures=args.textures, texture_size=args.texture_size)
         W, H = args.width or 3840, args.height or 2160
         v2w = scene.synthetic_camera()
     else:
@@ -119,6 +130,12 @@ def main():
     _r.release(); _h.release()
     upload_bytes = sum(b.nbytes for b in sb.buffers()) + 2 * sky.rgb.nbytes + sum(t.nbytes for t in sd.textures)
     setup_s = time.time() - t_setup
+    setup_done.set()
+
+    def note(msg):
+        if rank == 0:
+            print("[bench] %s (%.1f s)" % (msg, time.time() - t_setup), file=sys.stderr, flush=True)
+    note("scene resident on the device")
 
     def barrier():
         ctx.synchronize()
@@ -162,6 +179,7 @@ def main():
 
         for k in range(warmup):
             draw(1 + k, 0)
+        note("warm-up draws queued")
         accum_mode = 1 if world > 1 else 0
         if world > 1:
             for name in multigpu.ACCUMULATED:   # sums start from zero on every rank
@@ -177,6 +195,7 @@ def main():
             multigpu.allreduce_outputs(torch, dist, p, npix, total_spp, dev_tensor, via_cpu=args.rehearse)
         barrier()
         dt = time.perf_counter() - t0
+        note("timed region done")
         st = p.stats(reset=True)
         if args.dump and rank == 0:
             np.savez(args.dump, **p.download())
@@ -200,6 +219,7 @@ def main():
             pst = p.stats(reset=True)
             p.set_profiling(False)
             p.set_pipeline(args.pipeline)
+            note("per-kernel profiling pass done")
             prof["draws"] = n_prof
             prof["serial_ms_per_step"] = serial_ms
             # every BVH traversal launch of the draws: extend at vertex 0, then per vertex one launch
@@ -238,7 +258,7 @@ def main():
                     else "synthetic procedural scene + procedural 2048x1024 sky",
             "config": {"workload": {"casa_pt": "casa 1920x1080 path trace, 1 spp per step, max depth %d, sky NEE + BSDF sampling" % args.depth,
                                     "casa_isect": "intersection only: %d random incoherent rays vs casa BVH per step" % args.rays,
-                                    "synth_pt": "synthetic %d-triangle scene %dx%d path trace, 1 spp per step, max depth %d" % (len(sd.triangles), W, H, args.depth)}[wl],
+                                    "synth_pt": "synthetic %d-triangle scene %dx%d path trace, 1 spp per step, max depth %d, %d%% dielectric instances, %d textures of %d^2" % (len(sd.triangles), W, H, args.depth, round(args.dielectric * 100), args.textures, args.texture_size)}[wl],
                        "resolution": [W, H] if wl != "casa_isect" else None,
                        "triangles": int(len(sd.triangles)), "instances": int(len(sd.instances)),
                        "draws_in_flight": args.pipeline if wl != "casa_isect" else None,
@@ -277,9 +297,11 @@ def main():
                 s_last = steps
                 prm = scene.make_params(sw, sh, v2w, sky, spp=1, frame=s_last, jitter=jit[s_last - 1], max_depth=args.depth,
                                         light_count=len(sd.lights))
+                note("oracle scene built, rendering the CPU sample")
                 t1 = time.perf_counter()
                 ref, cnt = osc.render(prm, n_threads=cores)
                 cdt = time.perf_counter() - t1
+                note("CPU sample done")
                 c_rays = cnt["rays_extend"] + cnt["rays_shadow"]
                 b_ray = oracle.algorithmic_bytes_per_ray(cnt)  # extend and shadow rays together, as the launches trace them
                 if True:

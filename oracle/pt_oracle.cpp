@@ -586,6 +586,13 @@ struct Ctx {
     Intersection intersect_sceneBVH(const Ray &ray) {
         cnt.rays++;
         Intersection result;
+        // A ray with a NaN in its origin or direction (the reference's refract() and GGX
+        // sampling produce them: sqrt of a rounding-negative, math.glsl:27) cannot hit anything:
+        // every triangle test compares NaN and fails.  But NaN-dropping min/max make every box
+        // pass, so the walk below would visit the whole scene for nothing.  Same answer, no walk.
+        if(std::isnan(ray.ori.x) || std::isnan(ray.ori.y) || std::isnan(ray.ori.z) || std::isnan(ray.dir.x) ||
+           std::isnan(ray.dir.y) || std::isnan(ray.dir.z))
+            return result;
         stack_h = 0;
         stack[++stack_h] = 0;
         const Node *nodes = scene_nodes();

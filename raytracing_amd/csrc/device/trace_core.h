@@ -99,6 +99,14 @@ struct WaveRayFeed {
     }
 };
 
+// A ray with a NaN in its origin or direction cannot hit anything (every triangle test
+// compares NaN and fails), but NaN-dropping min/max let it pass every box: it would visit the
+// whole scene to report a miss.  Such rays (the reference's refract() makes them) are
+// finished as misses without a walk.
+__device__ __forceinline__ bool ray_has_nan(const float o[3], const float d[3]) {
+    return o[0] != o[0] || o[1] != o[1] || o[2] != o[2] || d[0] != d[0] || d[1] != d[1] || d[2] != d[2];
+}
+
 // Persistent-wave traversal.  Every lane owns one ray at a time; a lane whose ray is
 // finished takes the next ray index (WaveRayFeed) as soon as fewer than REFILL_BELOW lanes
 // of its wave are still busy,
@@ -144,6 +152,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                     float t0;
                     have = slab_test(sc.hdr.root_lo[0], sc.hdr.root_lo[1], sc.hdr.root_lo[2], sc.hdr.root_hi[0],
                                      sc.hdr.root_hi[1], sc.hdr.root_hi[2], wox, woy, woz, wdx, wdy, wdz, t0);
+                    if(ray_has_nan(o, d)) have = false;
                     ref = sc.hdr.root_ref;
                     tn = t0;
                 }

@@ -156,6 +156,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                                          sc.hdr.root_hi[1], sc.hdr.root_hi[2], wox, woy, woz, wdx, wdy, wdz, t0);
                         tn = t0;
                     }
+                    if(ray_has_nan(o, d)) have = false;  // a certain miss, see trace_core.h
                     ref = sc.hdr.root_ref;
                 }
             }

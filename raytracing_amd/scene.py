@@ -437,9 +437,11 @@ def _grid_mesh(pos, nu, nv, uv_scale=1.0):
     idx = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)], 0)
     P = pos.reshape(-1, 3)
     fn = np.cross(P[idx[:, 1]] - P[idx[:, 0]], P[idx[:, 2]] - P[idx[:, 0]])
-    vn = np.zeros_like(P)
+    vn = np.zeros(P.shape, np.float64)
     for k in range(3):
-        np.add.at(vn, idx[:, k], fn)
+        for c in range(3):
+            vn[:, c] += np.bincount(idx[:, k], weights=fn[:, c], minlength=len(P))
+    vn = vn.astype(np.float32)
     vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-20)
     gu, gv = np.meshgrid(np.arange(nu + 1) / nu, np.arange(nv + 1) / nv, indexing="ij")
     UV = (np.stack([gu, gv], -1).reshape(-1, 2) * uv_scale).astype(np.float32)
@@ -447,23 +449,45 @@ def _grid_mesh(pos, nu, nv, uv_scale=1.0):
     return np.ascontiguousarray(tri, np.float32)
 
 
-def synthetic_scene(n_tris=10_000_000, n_threads=0, seed=12345, dielectric_fraction=0.0, lights=0):
+def procedural_texture(size, seed, channels=4):
+    """size x size 8-bit texture: bands and cells with seeded colours (stands in for the 4K
+    albedo maps of the texture-heavy configuration)."""
+    rng = np.random.default_rng(1000 + seed)
+    y, x = np.mgrid[0:size, 0:size].astype(np.float32) / np.float32(size)
+    base = rng.random(3).astype(np.float32)
+    f = rng.integers(2, 9, 3)
+    img = np.empty((size, size, channels), np.float32)
+    for c in range(3):
+        img[..., c] = 0.15 + 0.8 * (0.5 + 0.5 * np.sin(6.2831853 * (f[c] * x + (c + 1) * y))) * base[c] \
+                      + 0.1 * (((x * 16).astype(np.int32) + (y * 16).astype(np.int32)) & 1)
+    if channels == 4:
+        img[..., 3] = 1.0
+    return np.ascontiguousarray(np.clip(img * 255.0, 0, 255).astype(np.uint8))
+
+
+def synthetic_scene(n_tris=10_000_000, n_threads=0, seed=12345, dielectric_fraction=0.0, lights=0, textures=0,
+                    texture_size=256):
     """Procedural stand-in for the large configurations: a 4 x 4 tiling of displaced terrain
     patches and 48 displaced spheres resting above it, 64 meshes / 64 instances in all,
     about n_tris triangles, conductor materials with seeded roughness 0.05..0.8 (a
     fraction may be rough dielectrics), optionally `lights` analytic lights (alternating
-    point and directional).  Deterministic for a given (n_tris, seed)."""
+    point and directional) and `textures` procedural RGBA8 albedo maps spread over the
+    instances.  Deterministic for a given argument list."""
     rng = np.random.default_rng(seed)
     per_mesh = max(8, n_tris // 64)
     k = max(2, int(round(math.sqrt(per_mesh / 2.0))))
     b = SceneBuilder()
     tile = 20.0
+    tex_ids = [b.add_texture(procedural_texture(texture_size, k)) for k in range(textures)]
+    n_mat = [0]
 
     def material():
         t = 2 if rng.random() < dielectric_fraction else 1
+        n_mat[0] += 1
         return dict(type=t, albedo=tuple(np.float32(0.2 + 0.75 * rng.random(3))),
                     roughness=np.float32(0.05 + 0.75 * rng.random()),
-                    metallic=np.float32(1.0 if rng.random() < 0.5 else 0.0), tex=-1,
+                    metallic=np.float32(1.0 if rng.random() < 0.5 else 0.0),
+                    tex=tex_ids[n_mat[0] % len(tex_ids)] if tex_ids and n_mat[0] % 4 != 0 else -1,
                     ior=np.float32(1.3 + 0.5 * rng.random()))
 
     def height(x, z):

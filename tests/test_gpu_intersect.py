@@ -80,5 +80,21 @@ def test_degenerate_rays(casa, oracle_mod, gpu_ctx):
     rays2 = np.concatenate([pos, d2], 1).astype(np.float32)
     ref2, _ = osc.intersect(rays2)
     _check(device.trace_rays(p, rays2), ref2)
+    # NaN / Inf / zero-vector rays (the reference's refract() returns vec3(0) and NaNs): both sides
+    # finish NaN rays as misses without walking the scene; the others go through the slab arithmetic
+    rays3 = rays[:4000].copy()
+    for k in range(6):
+        rays3[k::40, k] = np.nan
+    rays3[5::40, 3:] = 0.0
+    rays3[7::40, 3] = np.inf
+    rays3[9::40, 4] = -np.inf
+    rays3[11::40, 0] = np.inf
+    for mode in (0, 1):
+        p.set_traversal(mode)
+        ref3, _ = osc.intersect(rays3)
+        got3 = device.trace_rays(p, rays3)
+        _check(got3, ref3)
+        nan_rows = np.isnan(rays3).any(axis=1)
+        assert nan_rows.sum() >= 500 and (got3["triangle"][nan_rows] == -1).all()
     p.destroy()
     sb.release()

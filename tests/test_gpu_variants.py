@@ -18,7 +18,7 @@ def bit_equal(a, b):
 @pytest.fixture(scope="module")
 def mixed_scene():
     from raytracing_amd import scene
-    return scene.synthetic_scene(30_000, seed=99, dielectric_fraction=0.5, lights=3)
+    return scene.synthetic_scene(30_000, seed=99, dielectric_fraction=0.5, lights=3, textures=5, texture_size=64)
 
 
 def run(gpu_ctx, oracle_mod, sd, sky, w, h, spps, traversal=0, pipeline=3, **kw):
@@ -69,8 +69,9 @@ def test_depth_zero_and_deep(mixed_scene, small_sky, oracle_mod, gpu_ctx):
     out, ref, st, cnt = run(gpu_ctx, oracle_mod, mixed_scene, small_sky, 96, 54, [1], max_depth=0)
     check(out, ref, st, cnt)
     assert cnt["rays_shadow"] == 0
-    out, ref, st, cnt = run(gpu_ctx, oracle_mod, mixed_scene, small_sky, 64, 36, [1], max_depth=12)  # Sobol dimensions > 19
+    out, ref, st, cnt = run(gpu_ctx, oracle_mod, mixed_scene, small_sky, 64, 36, [1], max_depth=16)  # Sobol dimensions > 19
     check(out, ref, st, cnt)
+    assert cnt["ldr_tex_fetches"] > 0
 
 
 def test_reference_order_mode_and_pipeline_depths(mixed_scene, small_sky, oracle_mod, gpu_ctx):
