@@ -215,8 +215,8 @@ public:
         // 7..15 are the pass's own outputs (Renderer.cpp:42-50): nothing to bind
     }
     void bind_texture(const char *name, pt_tex *tex, int /*targetId*/, int /*type*/ = 0) override {
-        // the four raster G-buffer samplers (main.cpp:181-184) have no counterpart: primary rays are traced
-        if(!strcmp(name, "skybox") || !strcmp(name, "skybox_samplecache")) check(pt_pass_bind_texture(m_pass, name, tex));
+        // "skybox", "skybox_samplecache" and the four raster images (main.cpp:179-184)
+        check(pt_pass_bind_texture(m_pass, name, tex));
     }
 
     // the uniform block of main.cpp:185-205, by the shader's own names

@@ -35,7 +35,10 @@ class OrcScene(C.Structure):
     _fields_ = [("materials", C.c_void_p), ("triangles", C.c_void_p), ("instances", C.c_void_p),
                 ("mesh_nodes", C.c_void_p), ("scene_nodes", C.c_void_p), ("lights", C.c_void_p),
                 ("textures", C.POINTER(OrcTexture)), ("n_textures", C.c_int32),
-                ("skybox", OrcTexture), ("skybox_samplecache", OrcTexture)]
+                ("skybox", OrcTexture), ("skybox_samplecache", OrcTexture),
+                ("depthGBufferTexture", OrcTexture), ("normalGBufferTexture", OrcTexture),
+                ("uvGBufferTexture", OrcTexture), ("instanceIndexGBufferTexture", OrcTexture),
+                ("n_instances", C.c_int32)]
 
 
 class OrcOutputs(C.Structure):
@@ -113,9 +116,20 @@ class OracleScene:
         if sky is not None:
             s.skybox = _tex(sky.rgb, 1)
             s.skybox_samplecache = _tex(sky.cache, 1)
+        s.n_instances = len(sd.instances)
         self.c = s
         self.scene_data = sd
         self.sky = sky
+
+    def set_gbuffer(self, depth, normal, uv, instance_index):
+        """The raster pass's four float images (h x w x 1/3/2/1) for RasterizaionFor1st renders."""
+        imgs = [np.ascontiguousarray(a, np.float32) for a in (depth, normal, uv, instance_index)]
+        imgs = [a.reshape(a.shape[0], a.shape[1], -1) for a in imgs]
+        self._keep.append(imgs)
+        self.c.depthGBufferTexture = _tex(imgs[0], 1)
+        self.c.normalGBufferTexture = _tex(imgs[1], 1)
+        self.c.uvGBufferTexture = _tex(imgs[2], 1)
+        self.c.instanceIndexGBufferTexture = _tex(imgs[3], 1)
 
     def intersect(self, rays, n_threads=0):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

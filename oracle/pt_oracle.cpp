@@ -267,6 +267,24 @@ struct Ctx {
         if(tx.format == 0) cnt.ldr_tex_fetches++;
         else cnt.sky_fetches++;
     }
+    // NEAREST filter, REPEAT wrap (GL 4.6 core 8.14.2): red channel of texel floor(s * w), floor(t * h)
+    float texture_nearest(const orc_texture &tx, float s, float t) {
+        auto wrap = [](float f, int n) {
+            float c = std::fmin(std::fmax(f, -1073741824.0f), 1073741824.0f);
+            int m = (int)c % n;
+            return m < 0 ? m + n : m;
+        };
+        int i = wrap(std::floor(s * (float)tx.width), tx.width), j = wrap(std::floor(t * (float)tx.height), tx.height);
+        size_t base = ((size_t)j * tx.width + i) * tx.channels;
+        return tx.format == 0 ? (float)((const uint8_t *)tx.data)[base] / 255.0f : ((const float *)tx.data)[base];
+    }
+    // int(x) of GLSL is undefined outside the int range and for NaN: saturate, NaN -> 0
+    static int float_to_int(float x) {
+        if(x != x) return 0;
+        if(x >= 2147483520.0f) return 2147483647;
+        if(x <= -2147483648.0f) return (int)0x80000000;
+        return (int)x;
+    }
 
     vec3 albedo_texture(int albedo_map, vec2 uv) {
         float c[4];
@@ -769,10 +787,37 @@ struct Ctx {
         }
         Ray ray{ori, normalize(d)};
 
-        cnt.rays_extend++;
-        Intersection first_isect = intersect_sceneBVH(ray);  // RasterizaionFor1st == false branch, :626-628
-        float depth = first_isect.exist ? first_isect.t : 1000000.0f;
-        int instanceIndex = first_isect.instanceIndex;
+        Intersection first_isect;
+        float depth;
+        int instanceIndex;
+        if(pm->RasterizaionFor1st) {
+            // :606-624: the first hit comes from the raster pass's images
+            float suv_x0 = ((float)px + 0.5f) / (float)W, suv_y0 = ((float)py + 0.5f) / (float)H;
+            float wu = suv_x0 * (float)W / (float)pm->WINDOW_W;
+            float wv = (suv_y0 - 1.0f) * (float)H / (float)pm->WINDOW_H + 1.0f;
+            float c[4];
+            texture(sc->depthGBufferTexture, wu, wv, c);
+            depth = c[0];
+            instanceIndex = float_to_int(texture_nearest(sc->instanceIndexGBufferTexture, wu, wv) + 0.01f);
+            first_isect.t = depth;
+            first_isect.exist = depth <= 100000.0f;
+            texture(sc->normalGBufferTexture, wu, wv, c);
+            first_isect.normal = normalize(vec3(c[0], c[1], c[2]));
+            texture(sc->uvGBufferTexture, wu, wv, c);
+            first_isect.uv = {c[0], c[1]};
+            first_isect.position = ray.ori + ray.dir * first_isect.t;
+            first_isect.instanceIndex = instanceIndex;
+            // an index that names no instance would be an out-of-bounds read in the reference
+            // (:641); such a pixel is treated as not covered
+            if(instanceIndex < 0 || instanceIndex >= sc->n_instances) first_isect.exist = false;
+        } else {
+            cnt.rays_extend++;
+            first_isect = intersect_sceneBVH(ray);  // :626-628
+            // the reference keeps the raster depth / instance index here (:615-616, :684); without a
+            // raster pass they are those of the traced hit
+            depth = first_isect.exist ? first_isect.t : 1000000.0f;
+            instanceIndex = first_isect.instanceIndex;
+        }
 
         vec3 resultDI, resultGI, albedo;
         shade_mis_advanced(ray, first_isect, resultDI, resultGI);

@@ -57,6 +57,11 @@ typedef struct orc_scene {
     int32_t n_textures;
     orc_texture skybox;            /* f32 RGB */
     orc_texture skybox_samplecache; /* f32 RGB */
+    /* RasterizaionFor1st: what RasterPass draws (raster_ps.glsl:17-27), f32: distance along
+     * the primary ray (R), world normal (RGB, not normalised), uv (RG), instance index (R);
+     * cleared to 1e6 where nothing was drawn.  Only read when params->RasterizaionFor1st. */
+    orc_texture depthGBufferTexture, normalGBufferTexture, uvGBufferTexture, instanceIndexGBufferTexture;
+    int32_t n_instances; /* records in `instances`; bounds the raster instance index */
 } orc_scene;
 
 /* same field order as pt_params in include/raytracing_amd.h */

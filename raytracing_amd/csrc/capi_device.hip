@@ -107,6 +107,7 @@ struct pt_pass {
     uint64_t seen_version[7] = {};
     const pt_buf *seen_ptr[7] = {};
     pt_tex *sky = nullptr, *sky_cache = nullptr;
+    pt_tex *gb_depth = nullptr, *gb_normal = nullptr, *gb_uv = nullptr, *gb_inst = nullptr;  // RasterizaionFor1st inputs
     pt_params params;
     bool have_params = false;
     // derived scene
@@ -591,8 +592,8 @@ void *pt_buf_device_ptr(const pt_buf *buf) { return buf ? buf->dptr : nullptr; }
 // ------------------------------------------------------------------------------- textures
 int pt_tex_create(pt_ctx *ctx, int width, int height, int channels, int format, const void *data, pt_tex **out) {
     if(!ctx || !out || !data) return fail(PT_ERR_INVALID, "pt_tex_create: null argument");
-    if(width <= 0 || height <= 0 || (channels != 1 && channels != 3 && channels != 4))
-        return fail(PT_ERR_INVALID, "pt_tex_create: width/height must be positive and channels 1, 3 or 4");
+    if(width <= 0 || height <= 0 || channels < 1 || channels > 4 || (channels == 2 && format != PT_TEX_F32))
+        return fail(PT_ERR_INVALID, "pt_tex_create: width/height must be positive and channels 1, 3 or 4 (2 for float images)");
     if(format != PT_TEX_U8 && format != PT_TEX_F32) return fail(PT_ERR_INVALID, "pt_tex_create: unknown format");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)width * height * channels * (format == PT_TEX_F32 ? 4 : 1);
@@ -688,12 +689,22 @@ int pt_pass_bind(pt_pass *pass, int slot, pt_buf *buf) {
 int pt_pass_bind_texture(pt_pass *pass, const char *name, pt_tex *tex) {
     if(!pass || !name) return fail(PT_ERR_INVALID, "pt_pass_bind_texture: null argument");
     if(tex && tex->ctx != pass->ctx) return fail(PT_ERR_INVALID, "pt_pass_bind_texture: texture belongs to another context");
-    if(tex && (tex->format != PT_TEX_F32 || tex->channels != 3))
-        return fail(PT_ERR_INVALID, "pt_pass_bind_texture: sky textures must be 3-channel float");
-    if(!strcmp(name, "skybox")) pass->sky = tex;
-    else if(!strcmp(name, "skybox_samplecache")) pass->sky_cache = tex;
-    else return fail(PT_ERR_INVALID, std::string("pt_pass_bind_texture: unknown sampler name ") + name);
-    return PT_OK;
+    struct Slot { const char *name; pt_tex **where; int min_channels; bool exact; };
+    const Slot slots[] = {{"skybox", &pass->sky, 3, true},
+                          {"skybox_samplecache", &pass->sky_cache, 3, true},
+                          {"depthGBufferTexture", &pass->gb_depth, 1, false},
+                          {"normalGBufferTexture", &pass->gb_normal, 3, false},
+                          {"uvGBufferTexture", &pass->gb_uv, 2, false},
+                          {"instanceIndexGBufferTexture", &pass->gb_inst, 1, false}};
+    for(const Slot &sl : slots)
+        if(!strcmp(name, sl.name)) {
+            if(tex && (tex->format != PT_TEX_F32 || tex->channels < sl.min_channels || (sl.exact && tex->channels != sl.min_channels)))
+                return fail(PT_ERR_INVALID, std::string("pt_pass_bind_texture: ") + name + " must be a float texture with " +
+                                                (sl.exact ? "" : "at least ") + std::to_string(sl.min_channels) + " channels");
+            *sl.where = tex;
+            return PT_OK;
+        }
+    return fail(PT_ERR_INVALID, std::string("pt_pass_bind_texture: unknown sampler name ") + name);
 }
 
 int pt_pass_set_params(pt_pass *pass, const pt_params *params) {
@@ -704,8 +715,8 @@ int pt_pass_set_params(pt_pass *pass, const pt_params *params) {
         return fail(PT_ERR_INVALID, "pt_pass_set_params: MAX_DEPTH must be 0.." + std::to_string(MAX_PATH_DEPTH));
     if(params->lightCount < 0) return fail(PT_ERR_INVALID, "pt_pass_set_params: negative lightCount");
     if(params->accum_mode != 0 && params->accum_mode != 1) return fail(PT_ERR_INVALID, "pt_pass_set_params: accum_mode must be 0 or 1");
-    if(params->RasterizaionFor1st)
-        return fail(PT_ERR_UNSUPPORTED, "pt_pass_set_params: RasterizaionFor1st needs the raster G-buffer inputs, which this pass does not take; primary rays are traced");
+    if(params->RasterizaionFor1st && (params->WINDOW_W <= 0 || params->WINDOW_H <= 0))
+        return fail(PT_ERR_INVALID, "pt_pass_set_params: RasterizaionFor1st needs positive WINDOW_W / WINDOW_H");
     pass->params = *params;
     pass->have_params = true;
     return PT_OK;
@@ -723,6 +734,10 @@ int pt_pass_draw(pt_pass *p) {
     if(P.SkyboxLighting && P.SkyboxSampling && !p->sky_cache)
         return fail(PT_ERR_STATE, "pt_pass_draw: texture \"skybox_samplecache\" is not bound");
     if(P.SKY_W <= 0 || P.SKY_H <= 0) return fail(PT_ERR_INVALID, "pt_pass_draw: SKY_W / SKY_H must be positive");
+    const bool raster_first = P.RasterizaionFor1st != 0;
+    if(raster_first && (!p->gb_depth || !p->gb_normal || !p->gb_uv || !p->gb_inst))
+        return fail(PT_ERR_STATE, "pt_pass_draw: RasterizaionFor1st needs the textures depthGBufferTexture, normalGBufferTexture, "
+                                  "uvGBufferTexture and instanceIndexGBufferTexture");
     if(P.lightCount > 0) {
         pt_buf *lb = p->slots[PT_SLOT_LIGHT];
         if(!lb || lb->bytes < (size_t)P.lightCount * sizeof(LightInfo))
@@ -749,6 +764,13 @@ int pt_pass_draw(pt_pass *p) {
     dp.n_textures = p->n_textures;
     dp.sky = desc_of(p->sky);
     dp.sky_cache = p->sky_cache ? desc_of(p->sky_cache) : desc_of(p->sky);
+    if(raster_first) {
+        dp.gb_depth = desc_of(p->gb_depth);
+        dp.gb_normal = desc_of(p->gb_normal);
+        dp.gb_uv = desc_of(p->gb_uv);
+        dp.gb_inst = desc_of(p->gb_inst);
+    }
+    dp.n_instances = (int)p->scene_level.header.n_instances;
     dp.rays = static_cast<PathRay *>(L.rays.p);
     dp.hits = static_cast<PathHit *>(L.hits.p);
     dp.thr = static_cast<PathThroughput *>(L.thr.p);
@@ -798,7 +820,7 @@ int pt_pass_draw(pt_pass *p) {
             launch_extend(s, sc, p->trace_blocks, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
         }
     };
-    extend(0, q_in);
+    if(!raster_first) extend(0, q_in);  // with RasterizaionFor1st the first hit comes from the raster images
     for(int dep = 0; dep <= P.MAX_DEPTH; dep++) {
         unsigned *q_out = (dep & 1) ? qb : qa;
         // shading the first vertex writes the last-write outputs: after the previous draw's

@@ -23,6 +23,9 @@ struct DrawParams {
     const TexDesc *textures;
     int n_textures;
     TexDesc sky, sky_cache;
+    // RasterizaionFor1st: the raster pass's images (distance, world normal, uv, instance index)
+    TexDesc gb_depth, gb_normal, gb_uv, gb_inst;
+    int n_instances;
     // path state, one slot per pixel
     PathRay *rays;
     PathHit *hits;

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
     const bool skyL = P.SkyboxLighting != 0, skyS = P.SkyboxSampling != 0;
 
     if(blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&dp.stats[1], (unsigned long long)n);
+        // (with RasterizaionFor1st the first vertex comes from images: no rays were traced for it)
+        if(!(dep == 0 && P.RasterizaionFor1st != 0)) atomicAdd(&dp.stats[1], (unsigned long long)n);
         if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
     }
 
@@ -102,11 +103,34 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
         const float4 r0 = rp[0], r1 = rp[1];
         const V3 ray_o = v3(r0.x, r0.y, r0.z), ray_d = v3(r1.x, r1.y, r1.z);
         const float prev_cos = r0.w;  // |wo.z| of the BSDF sample this ray follows
-        const float4 *hp = reinterpret_cast<const float4 *>(dp.hits + i);
-        const float4 h0 = hp[0], h1 = hp[1];
-        const float hit_t = h0.x, hit_u = h0.y, hit_v = h0.z;
-        const int hit_tri = __float_as_int(h0.w), hit_inst = __float_as_int(h1.x);
-        const bool exist = hit_tri >= 0;
+        // RasterizaionFor1st: the first hit comes from the raster pass's images (:606-624), no
+        // primary ray was traced
+        const bool raster0 = dep == 0 && P.RasterizaionFor1st != 0;
+        float hit_t, hit_u = 0.0f, hit_v = 0.0f;
+        int hit_tri = -1, hit_inst;
+        bool exist;
+        V3 g_normal = v3(0.0f, 0.0f, 1.0f);
+        float g_uvx = 0.0f, g_uvy = 0.0f;
+        if(raster0) {
+            const float suv_x0 = ((float)px + 0.5f) / (float)dp.W, suv_y0 = ((float)py + 0.5f) / (float)dp.H;
+            const float wu = suv_x0 * (float)dp.W / (float)P.WINDOW_W;
+            const float wv = (suv_y0 - 1.0f) * (float)dp.H / (float)P.WINDOW_H + 1.0f;
+            hit_t = texture_rgb(dp.gb_depth, wu, wv).x;
+            hit_inst = float_to_int(texture_nearest_r(dp.gb_inst, wu, wv) + 0.01f);
+            g_normal = normalize(texture_rgb(dp.gb_normal, wu, wv));
+            const V3 guv = texture_rgb(dp.gb_uv, wu, wv);
+            g_uvx = guv.x;
+            g_uvy = guv.y;
+            // an index that names no instance is treated as "not covered" (out of bounds in the reference)
+            exist = hit_t <= 100000.0f && hit_inst >= 0 && hit_inst < dp.n_instances;
+        } else {
+            const float4 *hp = reinterpret_cast<const float4 *>(dp.hits + i);
+            const float4 h0 = hp[0], h1 = hp[1];
+            hit_t = h0.x; hit_u = h0.y; hit_v = h0.z;
+            hit_tri = __float_as_int(h0.w);
+            hit_inst = __float_as_int(h1.x);
+            exist = hit_tri >= 0;
+        }
         float4 *tp = reinterpret_cast<float4 *>(dp.thr + i);
         const float4 t0 = tp[0], t1 = tp[1];
         V3 history = v3(t0.x, t0.y, t0.z);
@@ -135,19 +159,21 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
                 float4 *a = reinterpret_cast<float4 *>(acc);
                 a[0] = make_float4(bg.x, bg.y, bg.z, 0.0f);
                 a[1] = make_float4(bg.x, bg.y, bg.z, 0.0f);
-                // motion vector of the default intersection's position (0,0,0), :652-655
+                // motion vector of the intersection's position, :652-655: (0,0,0) of the default
+                // Intersection for a traced miss, ori + dir * depth for an uncovered raster pixel
+                const V3 mp = raster0 ? ray_o + ray_d * hit_t : v3(0.0f);
                 const float *bp = P.backprojMat;
-                const float nx = (bp[0] * 0.0f + bp[4] * 0.0f) + (bp[8] * 0.0f + bp[12]);
-                const float ny = (bp[1] * 0.0f + bp[5] * 0.0f) + (bp[9] * 0.0f + bp[13]);
-                const float nw = (bp[3] * 0.0f + bp[7] * 0.0f) + (bp[11] * 0.0f + bp[15]);
+                const float nx = (bp[0] * mp.x + bp[4] * mp.y) + (bp[8] * mp.z + bp[12]);
+                const float ny = (bp[1] * mp.x + bp[5] * mp.y) + (bp[9] * mp.z + bp[13]);
+                const float nw = (bp[3] * mp.x + bp[7] * mp.y) + (bp[11] * mp.z + bp[15]);
                 const float suv_x = ((float)px + 0.5f) / (float)dp.W, suv_y = ((float)py + 0.5f) / (float)dp.H;
                 dp.o_motion[(size_t)i * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
                 dp.o_motion[(size_t)i * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
-                dp.o_depth[i] = 1000000.0f;
-                dp.o_normal[(size_t)i * 3] = 0.0f;
-                dp.o_normal[(size_t)i * 3 + 1] = 0.0f;
-                dp.o_normal[(size_t)i * 3 + 2] = 1.0f;
-                dp.o_inst[i] = -1.0f;
+                dp.o_depth[i] = raster0 ? hit_t : 1000000.0f;
+                dp.o_normal[(size_t)i * 3] = g_normal.x;
+                dp.o_normal[(size_t)i * 3 + 1] = g_normal.y;
+                dp.o_normal[(size_t)i * 3 + 2] = g_normal.z;
+                dp.o_inst[i] = raster0 ? (float)hit_inst : -1.0f;
                 continue;
             }
         } else {
@@ -168,17 +194,21 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
         if(dep >= P.MAX_DEPTH && dep != 0) continue;  // loop bound of :501 (the first hit's outputs are due even at MAX_DEPTH 0)
 
         // ---- geometry of the hit (what intersect_triangle / intersect_meshBVH return, :239-248, :275-276)
-        const float *tr = reinterpret_cast<const float *>(dp.tris + hit_tri);
-        const float wgt = 1.0f - hit_u - hit_v;
-        const V3 n0 = v3(tr[9], tr[10], tr[11]), n1 = v3(tr[12], tr[13], tr[14]), n2 = v3(tr[15], tr[16], tr[17]);
-        const V3 nloc = normalize(n0 * wgt + n1 * hit_u + n2 * hit_v);
-        const float uvx = tr[18] * wgt + tr[20] * hit_u + tr[22] * hit_v;
-        const float uvy = tr[19] * wgt + tr[21] * hit_u + tr[23] * hit_v;
         const InstAccel &ia = dp.inst[hit_inst];
-        const V3 nn = v3(nloc.x * ia.row[0][0] + nloc.y * ia.row[1][0] + nloc.z * ia.row[2][0],
-                         nloc.x * ia.row[0][1] + nloc.y * ia.row[1][1] + nloc.z * ia.row[2][1],
-                         nloc.x * ia.row[0][2] + nloc.y * ia.row[1][2] + nloc.z * ia.row[2][2]);
-        const V3 normal = normalize(nn);
+        V3 normal = g_normal;
+        float uvx = g_uvx, uvy = g_uvy;
+        if(!raster0) {
+            const float *tr = reinterpret_cast<const float *>(dp.tris + hit_tri);
+            const float wgt = 1.0f - hit_u - hit_v;
+            const V3 n0 = v3(tr[9], tr[10], tr[11]), n1 = v3(tr[12], tr[13], tr[14]), n2 = v3(tr[15], tr[16], tr[17]);
+            const V3 nloc = normalize(n0 * wgt + n1 * hit_u + n2 * hit_v);
+            uvx = tr[18] * wgt + tr[20] * hit_u + tr[22] * hit_v;
+            uvy = tr[19] * wgt + tr[21] * hit_u + tr[23] * hit_v;
+            const V3 nn = v3(nloc.x * ia.row[0][0] + nloc.y * ia.row[1][0] + nloc.z * ia.row[2][0],
+                             nloc.x * ia.row[0][1] + nloc.y * ia.row[1][1] + nloc.z * ia.row[2][1],
+                             nloc.x * ia.row[0][2] + nloc.y * ia.row[1][2] + nloc.z * ia.row[2][2]);
+            normal = normalize(nn);
+        }
         const V3 position = ray_o + hit_t * ray_d;
         const int materialPtr = ia.material_ptr;
 

@@ -129,6 +129,19 @@ __device__ __forceinline__ V3 texture_rgb(const TexDesc &tx, float s, float t) {
     return ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;
 }
 
+// NEAREST filter, REPEAT wrap: red channel of texel floor(s * w), floor(t * h)
+__device__ __forceinline__ float texture_nearest_r(const TexDesc &tx, float s, float t) {
+    const int i = wrap_texel(floorf(s * (float)tx.width), tx.width), j = wrap_texel(floorf(t * (float)tx.height), tx.height);
+    return fetch_texel_rgb(tx, i, j).x;
+}
+// int(x) of GLSL is undefined outside the int range and for NaN: saturate, NaN -> 0
+__device__ __forceinline__ int float_to_int(float x) {
+    if(x != x) return 0;
+    if(x >= 2147483520.0f) return 2147483647;
+    if(x <= -2147483648.0f) return (int)0x80000000;
+    return (int)x;
+}
+
 // ---- materials ----------------------------------------------------------------------------
 struct BSDFQueryRecord {  // S/materials/materials.glsl:62-71
     V3 wi, wo;

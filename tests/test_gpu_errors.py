@@ -38,14 +38,12 @@ def test_draw_preconditions(gpu_ctx, casa, small_sky):
     fails(lambda: p.set_params(bad), "SCREEN_W")
     bad = scene.make_params(w, h, scene.casa_camera(), small_sky, max_depth=65)
     fails(lambda: p.set_params(bad), "MAX_DEPTH")
-    bad = scene.make_params(w, h, scene.casa_camera(), small_sky, raster_first=True)
-    fails(lambda: p.set_params(bad), "RasterizaionFor1st")
     bad = scene.make_params(w, h, scene.casa_camera(), small_sky, light_count=2)
     p.set_params(bad)
     fails(p.draw, "lightCount")                 # more lights than the bound buffer holds
     fails(lambda: p.set_pipeline(0), "1..")
     fails(lambda: p.set_traversal(2), "mode")
-    fails(lambda: p.bind_texture("depthGBufferTexture", sb.sky_tex), "unknown sampler")
+    fails(lambda: p.bind_texture("albedoTexture", sb.sky_tex), "unknown sampler")
     p.destroy()
     sb.release()
 
