@@ -78,6 +78,9 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
     p[1] = make_float4(recv.x, recv.y, recv.z, __uint_as_float(flags));
 }
 
+// RASTER_FIRST: the instance launched for vertex 0 when the first hit comes from the raster images;
+// kept apart so that the common instance carries none of its registers.
+template <bool RASTER_FIRST>
 __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int dep, const unsigned *queue_in,
                                                             const unsigned *count_in, unsigned *queue_out,
                                                             unsigned *count_out, unsigned *shadow_queue,
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
 
     if(blockIdx.x == 0 && threadIdx.x == 0) {
         // (with RasterizaionFor1st the first vertex comes from images: no rays were traced for it)
-        if(!(dep == 0 && P.RasterizaionFor1st != 0)) atomicAdd(&dp.stats[1], (unsigned long long)n);
+        if(!RASTER_FIRST) atomicAdd(&dp.stats[1], (unsigned long long)n);
         if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
     }
 
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
         const float prev_cos = r0.w;  // |wo.z| of the BSDF sample this ray follows
         // RasterizaionFor1st: the first hit comes from the raster pass's images (:606-624), no
         // primary ray was traced
-        const bool raster0 = dep == 0 && P.RasterizaionFor1st != 0;
+        const bool raster0 = RASTER_FIRST;
         float hit_t, hit_u = 0.0f, hit_v = 0.0f;
         int hit_tri = -1, hit_inst;
         bool exist;
@@ -396,8 +399,12 @@ void launch_generate(hipStream_t s, const DrawParams &dp) {
 
 void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,
                   unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count) {
-    hipLaunchKernelGGL(shade_kernel, dim3(shade_grid(dp.npix)), dim3(SHADE_BLOCK), 0, s, dp, dep, queue_in, count_in,
-                       queue_out, count_out, shadow_queue, shadow_count);
+    if(dep == 0 && dp.p.RasterizaionFor1st != 0)
+        hipLaunchKernelGGL(shade_kernel<true>, dim3(shade_grid(dp.npix)), dim3(SHADE_BLOCK), 0, s, dp, dep, queue_in, count_in,
+                           queue_out, count_out, shadow_queue, shadow_count);
+    else
+        hipLaunchKernelGGL(shade_kernel<false>, dim3(shade_grid(dp.npix)), dim3(SHADE_BLOCK), 0, s, dp, dep, queue_in, count_in,
+                           queue_out, count_out, shadow_queue, shadow_count);
 }
 
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,

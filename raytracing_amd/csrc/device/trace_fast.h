@@ -229,7 +229,8 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 in_mesh = false;
             }
 
-            if(is_inner) {
+            // one inner node: both child boxes, nearer child next, farther one deferred
+            auto inner_step = [&](const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3, bool scene_level) {
                 float t0, t1, x0, x1;
                 slab_range(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, x0);
                 slab_range(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cix, ciy, ciz, t1, x1);
@@ -242,7 +243,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 if(k1 == REF_TRIANGLE) { p1 = true; t1 = tn; }
                 // an instance child (scene level only): its box is the scene leaf box, whose
                 // EXACT test decides whether anything inside the instance is a candidate
-                if(kind == REF_SCENE_INNER) {
+                if(scene_level) {
                     if(k0 == REF_INSTANCE && p0 && !clear_pass(t0, x0)) {
                         float te;
                         p0 = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cdx, cdy, cdz, te);
@@ -280,6 +281,9 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 } else {
                     have = false;
                 }
+            };
+            if(is_inner) {
+                inner_step(q0, q1, q2, q3, kind == REF_SCENE_INNER);
             } else if(serve_inst && is_inst) {
                 // entry into the instance: rows of world-to-local, then the mesh root
                 cox = (q0.x * wox + q0.y * woy) + (q0.z * woz + q0.w);
