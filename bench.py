@@ -320,7 +320,7 @@ def main():
                     out["parity_vs_oracle"] = ("all 7 outputs bit-equal for sample %d at %dx%d" % (s_last, sw, sh)) if same else "MISMATCH"
                 out["cpu_baseline"] = {"value": c_rays / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
                                        "sample": "1 spp of the same frame at %dx%d (%d rays), OpenMP over rows" % (sw, sh, c_rays)}
-                out["algorithmic_bytes"] = {"per_extend_ray": b_ray,
+                out["algorithmic_bytes"] = {"per_extend_ray": oracle.algorithmic_bytes_per_extend_ray(cnt),
                                             "per_any_ray": oracle.algorithmic_bytes_per_ray(cnt)}
         # ---- roofline of the dominant kernel
         if dominant is not None and dominant[2] > 0:
