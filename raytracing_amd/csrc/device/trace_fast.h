@@ -124,7 +124,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
     float tn = 0;
 
 #ifdef RT_TRACE_STATS
-    unsigned long long st_slots = 0, st_inner = 0, st_leaf = 0, st_inst = 0;
+    unsigned long long st_slots = 0, st_inner = 0, st_leaf = 0, st_inst = 0, st_iter = 0, st_leaf_runs = 0, st_inst_runs = 0;
 #endif
     for(;;) {
         {
@@ -205,6 +205,14 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
             const bool go = is_inner || (is_leaf && serve_leaf) || (is_inst && serve_inst);
 #ifdef RT_TRACE_STATS
             st_slots += 1;
+            {
+                const bool leaf_runs = serve_leaf && __ballot(is_leaf) != 0ull, inst_runs = serve_inst && __ballot(is_inst) != 0ull;
+                if((threadIdx.x & 63u) == 0u) {
+                    st_iter++;
+                    if(leaf_runs) st_leaf_runs++;
+                    if(inst_runs) st_inst_runs++;
+                }
+            }
             if(go) {
                 if(kind == REF_TRIANGLE) st_leaf++;
                 else if(kind == REF_INSTANCE) st_inst++;
@@ -336,9 +344,15 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
     }
 #ifdef RT_TRACE_STATS
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(sc.error_flag + 4);
-    atomicAdd(dbg + 0, st_slots);
-    atomicAdd(dbg + 1, st_inner + st_inst);
-    atomicAdd(dbg + 2, st_leaf);
+    if(RT_TRACE_STATS == 2) {  // wave-level: iterations, iterations that ran the leaf / instance code
+        atomicAdd(dbg + 0, st_iter);
+        atomicAdd(dbg + 1, st_leaf_runs);
+        atomicAdd(dbg + 2, st_inst_runs);
+    } else {
+        atomicAdd(dbg + 0, st_slots);
+        atomicAdd(dbg + 1, st_inner + st_inst);
+        atomicAdd(dbg + 2, st_leaf);
+    }
 #endif
 }
 
