@@ -29,6 +29,9 @@ struct pt_ctx {
     // Draws run on streams of their own (pt_pass::lanes).  Each leaves its completion event
     // here; everything issued on `stream` first makes `stream` wait for them (ctx_join).
     std::vector<hipEvent_t> pending;
+    // live passes: a buffer or texture that is released is unbound from them first, so that a
+    // later draw reports the missing binding instead of reading freed memory
+    std::vector<pt_pass *> passes;
 };
 
 // Orders the context's main stream behind every draw issued so far.
@@ -154,6 +157,24 @@ struct pt_pass {
 };
 
 namespace {
+
+void unbind_everywhere(pt_ctx *ctx, const pt_buf *buf, const pt_tex *tex) {
+    for(pt_pass *p : ctx->passes) {
+        if(buf)
+            for(int k = 0; k < 7; k++)
+                if(p->slots[k] == buf) {
+                    p->slots[k] = nullptr;
+                    p->seen_ptr[k] = nullptr;
+                }
+        if(tex) {
+            for(pt_tex **t : {&p->sky, &p->sky_cache, &p->gb_depth, &p->gb_normal, &p->gb_uv, &p->gb_inst})
+                if(*t == tex) *t = nullptr;
+            // the descriptor table built from the handle buffer may name it: rebuild at the next draw,
+            // which then reports the dead handle
+            p->seen_version[PT_SLOT_TEXTURE_HANDLES] = ~0ull;
+        }
+    }
+}
 
 // The bytes of a buffer on the host: its upload shadow when there is one (no copy), else a
 // download into `tmp`.
@@ -517,6 +538,7 @@ int pt_buf_release(pt_buf *buf) {
     (void)hipSetDevice(buf->ctx->device);
     (void)ctx_join(buf->ctx);
     (void)hipStreamSynchronize(buf->ctx->stream);
+    unbind_everywhere(buf->ctx, buf, nullptr);
     if(buf->dptr) (void)hipFree(buf->dptr);
     delete buf;
     return PT_OK;
@@ -619,6 +641,7 @@ int pt_tex_release(pt_tex *tex) {
     (void)hipSetDevice(tex->ctx->device);
     (void)ctx_join(tex->ctx);
     (void)hipStreamSynchronize(tex->ctx->stream);
+    unbind_everywhere(tex->ctx, nullptr, tex);
     tex->ctx->textures.erase(tex->handle);
     if(tex->dptr) (void)hipFree(tex->dptr);
     delete tex;
@@ -658,12 +681,18 @@ int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
         pt_pass_destroy(p);
         return rc;
     }
+    ctx->passes.push_back(p);
     *out = p;
     return PT_OK;
 }
 
 int pt_pass_destroy(pt_pass *p) {
     if(!p) return PT_OK;
+    for(size_t k = 0; k < p->ctx->passes.size(); k++)
+        if(p->ctx->passes[k] == p) {
+            p->ctx->passes.erase(p->ctx->passes.begin() + (long)k);
+            break;
+        }
     (void)hipSetDevice(p->ctx->device);
     (void)ctx_join(p->ctx);
     (void)hipStreamSynchronize(p->ctx->stream);

@@ -119,3 +119,26 @@ def test_buffer_and_intersect_argument_checks(gpu_ctx, casa, small_sky):
         x.release()
     p.destroy()
     sb.release()
+
+
+def test_released_resources_are_unbound_not_dangling(gpu_ctx, casa, small_sky):
+    """Releasing a buffer or texture that a pass still has bound (the reference's release();
+    x = SSBOBuffer(...) pattern, ResourceManager.cpp:53-54, forgets to rebind) makes the next draw
+    fail with a message instead of reading freed memory."""
+    from raytracing_amd import device, scene
+    w, h = 32, 18
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    p.set_params(scene.make_params(w, h, scene.casa_camera(), small_sky))
+    p.draw()
+    sb.textures[0].release()                    # an albedo map named by the handle buffer
+    fails(p.draw, "live texture")
+    sb.sky_cache_tex.release()
+    sb.sky_cache_tex = None
+    fails(p.draw, "live texture")               # still the first problem found
+    sb.materialSSBO.release()
+    fails(p.draw, "slot 1")
+    p.destroy()
+    sb.textures = sb.textures[1:]
+    sb.release()
