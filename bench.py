@@ -182,6 +182,10 @@ def main():
         note("warm-up draws queued")
         accum_mode = 1 if world > 1 else 0
         if world > 1:
+            # warm the collective up too (communicator, channels, staging buffers): its first use
+            # costs far more than the later ones and does not belong to the frame
+            ctx.synchronize()
+            multigpu.allreduce_outputs(torch, dist, p, npix, max(warmup, 1) * world, dev_tensor, via_cpu=args.rehearse)
             for name in multigpu.ACCUMULATED:   # sums start from zero on every rank
                 p.outputs[name].fill(0.0)
         p.set_pipeline(args.pipeline)
