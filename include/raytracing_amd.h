@@ -237,6 +237,36 @@ int pt_post_static_blend(pt_ctx *ctx, uint32_t frame_counter, const pt_buf *colo
                          pt_buf *history_moment);
 int pt_post_tonemap(pt_ctx *ctx, const pt_buf *color, pt_buf *out);
 
+/* ---- denoising chain: one call per shader dispatch of the reference's SVGF and TAA passes ----
+ * width x height is the render target; every buffer holds width*height pixels of the channel
+ * count given (c3 = 3 floats per pixel ...).  Outputs must not alias inputs.  The history
+ * copies that the reference's pass classes make after the dispatch (SVGFTemporalFilter.cpp:47-51,
+ * TAA.cpp:38-40) are plain pt_buf_copy calls and stay with the caller (include/raytracing_amd.hpp
+ * has the classes).
+ *
+ * pt_post_svgf_temporal: SVGF_TemporalFilter.glsl:124-200.  first_frame is the shader's uniform
+ *   (SVGFTemporalFilter::draw always passes false, SVGFTemporalFilter.cpp:30-31).
+ *   in: color c3, normal c3, instance_index c1, motion c2; history color c3, moment c2,
+ *   num_samples c1, normal c3, instance_index c1.  out: color c3, moment c2, num_samples c1.
+ * pt_post_svgf_variance: SVGF_VarianceFilter.glsl:30-103.  in: moment c2, normal c3, depth c1,
+ *   num_samples c1; out: variance c1.
+ * pt_post_svgf_spatial: one a-trous level, SVGF_SpatialFilter.glsl:32-90; step = 1 << level.
+ *   in: color c3, normal c3, depth c1, variance c1; out: color c3.
+ * pt_post_taa: TAA.glsl:124-190.  in: color c3 (LDR), history color c3, motion c2, normal c3,
+ *   instance_index c1, history normal c3, history instance_index c1; out: color c3. */
+int pt_post_svgf_temporal(pt_ctx *ctx, int width, int height, int first_frame, const pt_buf *color, const pt_buf *normal,
+                          const pt_buf *instance_index, const pt_buf *motion, pt_buf *out_color, pt_buf *out_moment,
+                          pt_buf *out_num_samples, const pt_buf *history_color, const pt_buf *history_moment,
+                          const pt_buf *history_num_samples, const pt_buf *history_normal,
+                          const pt_buf *history_instance_index);
+int pt_post_svgf_variance(pt_ctx *ctx, int width, int height, const pt_buf *moment, const pt_buf *normal, const pt_buf *depth,
+                          const pt_buf *num_samples, pt_buf *out_variance);
+int pt_post_svgf_spatial(pt_ctx *ctx, int width, int height, int step, const pt_buf *color, const pt_buf *normal,
+                         const pt_buf *depth, const pt_buf *variance, pt_buf *out_color);
+int pt_post_taa(pt_ctx *ctx, int width, int height, const pt_buf *color, const pt_buf *history_color, const pt_buf *motion,
+                const pt_buf *normal, const pt_buf *instance_index, const pt_buf *history_normal,
+                const pt_buf *history_instance_index, pt_buf *out_color);
+
 /* SSBOBuffer<float>::save_as_image (src/SSBOBuffer.h:41-62): bytes = min(255, int(x * 255)),
  * rows flipped (buffers hold the bottom row first), written as an 8-bit PNG (the reference
  * lets OpenCV pick the format from the file name; only PNG is written here).  channel is 1, 3

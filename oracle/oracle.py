@@ -82,6 +82,10 @@ def lib():
         _lib.orc_post_static_blend.argtypes = [C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_post_tonemap.restype = None
         _lib.orc_post_tonemap.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
+        for name, n_int, n_ptr in (("orc_svgf_temporal", 3, 12), ("orc_svgf_variance", 2, 5), ("orc_svgf_spatial", 3, 5), ("orc_taa", 2, 8)):
+            f = getattr(_lib, name)
+            f.restype = None
+            f.argtypes = [C.c_int] * n_int + [C.c_void_p] * n_ptr
         _lib.orc_quantize_image.restype = None
         _lib.orc_quantize_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return _lib
@@ -189,6 +193,41 @@ def quantize_image(data, w, h, c):
     out = np.zeros(w * h * c, np.uint8)
     lib().orc_quantize_image(data.ctypes.data, w, h, c, out.ctypes.data)
     return out.reshape(h, w, c)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32).ravel()
+
+
+def svgf_temporal(w, h, first_frame, color, normal, inst, motion, h_color, h_moment, h_num, h_normal, h_inst):
+    """SVGF_TemporalFilter.glsl: returns (color, moment, num_samples)."""
+    ins = [_f32(a) for a in (color, normal, inst, motion)]
+    hist = [_f32(a) for a in (h_color, h_moment, h_num, h_normal, h_inst)]
+    oc, om, on = np.zeros(w * h * 3, np.float32), np.zeros(w * h * 2, np.float32), np.zeros(w * h, np.float32)
+    lib().orc_svgf_temporal(w, h, int(first_frame), *[a.ctypes.data for a in ins], oc.ctypes.data, om.ctypes.data, on.ctypes.data,
+                            *[a.ctypes.data for a in hist])
+    return oc, om, on
+
+
+def svgf_variance(w, h, moment, normal, depth, num):
+    ins = [_f32(a) for a in (moment, normal, depth, num)]
+    out = np.zeros(w * h, np.float32)
+    lib().orc_svgf_variance(w, h, *[a.ctypes.data for a in ins], out.ctypes.data)
+    return out
+
+
+def svgf_spatial(w, h, step, color, normal, depth, variance):
+    ins = [_f32(a) for a in (color, normal, depth, variance)]
+    out = np.zeros(w * h * 3, np.float32)
+    lib().orc_svgf_spatial(w, h, int(step), *[a.ctypes.data for a in ins], out.ctypes.data)
+    return out
+
+
+def taa(w, h, color, h_color, motion, normal, inst, h_normal, h_inst):
+    ins = [_f32(a) for a in (color, h_color, motion, normal, inst, h_normal, h_inst)]
+    out = np.zeros(w * h * 3, np.float32)
+    lib().orc_taa(w, h, *[a.ctypes.data for a in ins], out.ctypes.data)
+    return out
 
 
 def algorithmic_bytes_per_ray(cnt):

@@ -1056,4 +1056,225 @@ void orc_quantize_image(const float *data, int w, int h, int c, uint8_t *out) {
         }
 }
 
+// ---------------------------------------------------------------- denoising chain
+namespace {
+inline float m_exp(float x) { return m_exp2(x * 1.44269504088896341f); }
+inline vec3 rd3(const float *b, long long ptr) { return vec3(b[ptr * 3 + 0], b[ptr * 3 + 1], b[ptr * 3 + 2]); }
+inline void wr3(float *b, long long ptr, vec3 v) { b[ptr * 3 + 0] = v.x; b[ptr * 3 + 1] = v.y; b[ptr * 3 + 2] = v.z; }
+inline float lumf(vec3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
+// int(x): undefined in GLSL outside the int range; saturating, NaN -> 0
+inline int to_int(float x) {
+    if(x != x) return 0;
+    if(x >= 2147483520.0f) return 2147483647;
+    if(x <= -2147483648.0f) return (int)0x80000000;
+    return (int)x;
+}
+// geometry_test, SVGF_TemporalFilter.glsl:50-65 and TAA.glsl:64-79
+inline bool same_surface(const float *normal, const float *inst, const float *h_normal, const float *h_inst, long long p1, long long p2) {
+    return dot(rd3(normal, p1), rd3(h_normal, p2)) > 0.9f && std::fabs(inst[p1] - h_inst[p2]) < 0.1f;
+}
+const float k_atrous[4] = {3.0f / 8, 1.0f / 4.0f, 1.0f / 16, 1.0f / 32};
+}  // namespace
+
+void orc_svgf_temporal(int W, int H, int first_frame, const float *colorB, const float *normal, const float *inst,
+                       const float *motionB, float *o_color, float *o_moment, float *o_num, const float *h_color,
+                       const float *h_moment, const float *h_num, const float *h_normal, const float *h_inst) {
+    for(int py = 0; py < H; py++)
+        for(int px = 0; px < W; px++) {
+            const long long pixelPtr = (long long)py * W + px;
+            const float su = ((float)px + 0.5f) / (float)W, sv = ((float)py + 0.5f) / (float)H;
+            vec3 color = rd3(colorB, pixelPtr);
+            float lum = lumf(color);
+            float mx = lum, my = lum * lum;
+            float motx = motionB[pixelPtr * 2], moty = motionB[pixelPtr * 2 + 1];
+            if(first_frame) {
+                wr3(o_color, pixelPtr, color);
+                o_moment[pixelPtr * 2] = mx; o_moment[pixelPtr * 2 + 1] = my;
+                o_num[pixelPtr] = 1.0f;
+                continue;
+            }
+            vec3 mu(0.0f), var(0.0f);
+            int nv = 0;
+            for(int i = 0; i < 9; i++) {
+                int ix = px + (i / 3 - 1), iy = py + (i % 3 - 1);
+                if(ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
+                vec3 r = rd3(colorB, (long long)iy * W + ix);
+                nv++;
+                mu = mu + r;
+                var = var + r * r;
+            }
+            mu = mu / (float)nv;
+            var = vmax(vec3(0.0f), var / (float)nv - mu * mu);
+            vec3 sigma = vec3(std::sqrt(var.x), std::sqrt(var.y), std::sqrt(var.z)) * 5.0f;
+
+            float lu = su - motx, lv = sv - moty;
+            if(lu >= 1.0f || lv >= 1.0f || lu < 0.0f || lv < 0.0f) {
+                o_num[pixelPtr] = 1.0f;
+            } else {
+                int lix = to_int(lu * (float)W), liy = to_int(lv * (float)H);
+                long long lastPixelPtr = (long long)liy * W + lix;
+                // interpolate(last_uv, pixelPtr, ...)
+                int lbx = to_int(std::floor(lu * (float)W - 0.5f)), lby = to_int(std::floor(lv * (float)H - 0.5f));
+                float pointx = lu * (float)W, pointy = lv * (float)H;
+                vec3 outcolor(0.0f);
+                float omx = 0.0f, omy = 0.0f, tot = 0.0f;
+                for(int i = 0; i < 4; i++) {
+                    long long ix = (long long)lbx + i / 2, iy = (long long)lby + i % 2;
+                    if(ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
+                    long long ptr = iy * W + ix;
+                    if(!same_surface(normal, inst, h_normal, h_inst, pixelPtr, ptr)) continue;
+                    float dx = std::fabs(pointx - (float)ix - 0.5f), dy = std::fabs(pointy - (float)iy - 0.5f);
+                    float weight = std::fmax(0.0f, (1.0f - dx) * (1.0f - dy));
+                    outcolor = outcolor + rd3(h_color, ptr) * weight;
+                    omx += h_moment[ptr * 2] * weight;
+                    omy += h_moment[ptr * 2 + 1] * weight;
+                    tot += weight;
+                }
+                vec3 lastcolor = outcolor / tot;
+                float lmx = omx / tot, lmy = omy / tot;
+                bool valid = tot > 0.00001f;
+                vec3 dir = lastcolor - mu;
+                if(!valid || std::fabs(dir.x) > sigma.x || std::fabs(dir.y) > sigma.y || std::fabs(dir.z) > sigma.z) {
+                    o_num[pixelPtr] = 1.0f;
+                } else {
+                    if(lix < 0 || lix >= W || liy < 0 || liy >= H) lastPixelPtr = pixelPtr;
+                    float historyLen = h_num[lastPixelPtr];
+                    o_num[pixelPtr] = historyLen + 1.0f;
+                    color = mixv(lastcolor, color, 0.2f);
+                    mx = mixf(lmx, mx, 0.2f);
+                    my = mixf(lmy, my, 0.2f);
+                }
+            }
+            wr3(o_color, pixelPtr, color);
+            o_moment[pixelPtr * 2] = mx; o_moment[pixelPtr * 2 + 1] = my;
+        }
+}
+
+void orc_svgf_variance(int W, int H, const float *momentB, const float *normalB, const float *depthB, const float *numB,
+                       float *variance) {
+    for(int py = 0; py < H; py++)
+        for(int px = 0; px < W; px++) {
+            const long long pixelPtr = (long long)py * W + px;
+            vec3 normal = rd3(normalB, pixelPtr);
+            float depth = depthB[pixelPtr];
+            float totalWeight = 0.0f, rx = 0.0f, ry = 0.0f;
+            const int reach = numB[pixelPtr] <= 4.0f ? 3 : 1;
+            for(int i = -reach; i <= reach; i++)
+                for(int j = -reach; j <= reach; j++) {
+                    int ix = px + i, iy = py + j;
+                    if(ix >= W || ix < 0 || iy >= H || iy < 0) continue;
+                    long long ptr = (long long)iy * W + ix;
+                    float w = k_atrous[std::abs(i)] * k_atrous[std::abs(j)];
+                    if(reach == 3)
+                        w = w * m_pow(std::fmax(0.0f, dot(normal, rd3(normalB, ptr))), 128.0f) * m_exp(-std::fabs(depth - depthB[ptr]) / 2.0f);
+                    totalWeight += w;
+                    rx += w * momentB[ptr * 2];
+                    ry += w * momentB[ptr * 2 + 1];
+                }
+            float mx = rx / totalWeight, my = ry / totalWeight;
+            variance[pixelPtr] = std::fmax(0.0f, my - mx * mx);
+        }
+}
+
+void orc_svgf_spatial(int W, int H, int step, const float *colorB, const float *normalB, const float *depthB,
+                      const float *varianceB, float *out) {
+    for(int py = 0; py < H; py++)
+        for(int px = 0; px < W; px++) {
+            const long long pixelPtr = (long long)py * W + px;
+            vec3 color = rd3(colorB, pixelPtr), normal = rd3(normalB, pixelPtr);
+            float depth = depthB[pixelPtr];
+            float sigma = std::sqrt(varianceB[pixelPtr]);
+            float totalWeight = 0.0f;
+            vec3 result(0.0f);
+            for(int i = -2; i <= 2; i++)
+                for(int j = -2; j <= 2; j++) {
+                    long long ix = px + (long long)i * step, iy = py + (long long)j * step;
+                    if(ix >= W || ix < 0 || iy >= H || iy < 0) continue;
+                    long long ptr = iy * W + ix;
+                    vec3 c2 = rd3(colorB, ptr);
+                    vec3 diff = color - c2;
+                    float len = std::sqrt(dot(diff, diff));
+                    float w = k_atrous[std::abs(i)] * k_atrous[std::abs(j)] *
+                              m_pow(std::fmax(0.0f, dot(normal, rd3(normalB, ptr))), 128.0f) *
+                              m_exp(-std::fabs(depth - depthB[ptr]) / 2.0f) *
+                              m_exp(-std::fabs(len) / (sigma * 4.0f + 0.00001f));
+                    totalWeight += w;
+                    result = result + w * c2;
+                }
+            result = result / totalWeight;
+            if(any_nan(result) || std::isinf(result.x) || std::isinf(result.y) || std::isinf(result.z)) result = vec3(10000.0f, 0.0f, 0.0f);
+            wr3(out, pixelPtr, result);
+        }
+}
+
+namespace {
+vec3 RGB2YCoCgR(vec3 c) {  // TAA.glsl:40-50
+    vec3 o;
+    o.y = c.x - c.z;
+    float temp = c.z + o.y / 2.0f;
+    o.z = c.y - temp;
+    o.x = temp + o.z / 2.0f;
+    return o;
+}
+vec3 YCoCgR2RGB(vec3 c) {  // :52-62
+    vec3 o;
+    float temp = c.x - c.z / 2.0f;
+    o.y = c.z + temp;
+    o.z = temp - c.y / 2.0f;
+    o.x = o.z + c.y;
+    return o;
+}
+}  // namespace
+
+void orc_taa(int W, int H, const float *colorB, const float *h_color, const float *motionB, const float *normal,
+             const float *inst, const float *h_normal, const float *h_inst, float *out) {
+    for(int py = 0; py < H; py++)
+        for(int px = 0; px < W; px++) {
+            const long long pixelPtr = (long long)py * W + px;
+            const float su = ((float)px + 0.5f) / (float)W, sv = ((float)py + 0.5f) / (float)H;
+            vec3 cur = rd3(colorB, pixelPtr);
+            vec3 mu(0.0f), var(0.0f);
+            int nv = 0;
+            for(int i = 0; i < 9; i++) {
+                int ix = px + (i / 3 - 1), iy = py + (i % 3 - 1);
+                if(ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
+                vec3 r = RGB2YCoCgR(rd3(colorB, (long long)iy * W + ix));
+                nv++;
+                mu = mu + r;
+                var = var + r * r;
+            }
+            mu = mu / (float)nv;
+            var = vmax(vec3(0.0f), var / (float)nv - mu * mu);
+            vec3 sigma(std::sqrt(var.x), std::sqrt(var.y), std::sqrt(var.z));
+            float lu = su - motionB[pixelPtr * 2], lv = sv - motionB[pixelPtr * 2 + 1];
+            // interpolate(last_uv, pixelPtr, mu, sigma, lastcolor)
+            int lbx = to_int(lu * (float)W - 0.5f), lby = to_int(lv * (float)H - 0.5f);
+            float pointx = lu * (float)W, pointy = lv * (float)H;
+            vec3 outcolor(0.0f);
+            float tot = 0.0f;
+            for(int i = 0; i < 4; i++) {
+                long long ix = (long long)lbx + i / 2, iy = (long long)lby + i % 2;
+                if(ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
+                long long ptr = iy * W + ix;
+                if(!same_surface(normal, inst, h_normal, h_inst, pixelPtr, ptr)) continue;
+                float dx = std::fabs(pointx - (float)ix - 0.5f), dy = std::fabs(pointy - (float)iy - 0.5f);
+                float weight = std::fmax(0.0f, (1.0f - dx) * (1.0f - dy));
+                vec3 lastcolor = RGB2YCoCgR(rd3(h_color, ptr));
+                vec3 dir = lastcolor - mu;
+                float milen = 1.0f;
+                milen = std::fmin(milen, sigma.x / std::fabs(dir.x));
+                milen = std::fmin(milen, sigma.y / std::fabs(dir.y));
+                milen = std::fmin(milen, sigma.z / std::fabs(dir.z));
+                lastcolor = YCoCgR2RGB(mu + dir * milen);
+                outcolor = outcolor + lastcolor * weight;
+                tot += weight;
+            }
+            vec3 lastcolor = outcolor / tot;
+            vec3 result = tot > 0.00001f ? mixv(lastcolor, cur, 0.05f) : cur;
+            if(result.x < 0.0f || result.y < 0.0f || result.z < 0.0f) result = vec3(0.0f);
+            if(any_nan(result)) result = vec3(0.0f);
+            wr3(out, pixelPtr, result);
+        }
+}
+
 }  // extern "C"

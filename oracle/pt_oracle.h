@@ -144,6 +144,19 @@ void orc_post_static_blend(size_t npix, uint32_t frame, const float *color, floa
 void orc_post_tonemap(size_t n, const float *in, float *out);
 void orc_quantize_image(const float *data, int w, int h, int c, uint8_t *out);
 
+/* The denoising chain, one call per shader dispatch (buffers as the shaders bind them):
+ * SVGF_TemporalFilter.glsl:124-200, SVGF_VarianceFilter.glsl:30-103, SVGF_SpatialFilter.glsl:32-90,
+ * TAA.glsl:124-190. */
+void orc_svgf_temporal(int W, int H, int first_frame, const float *color, const float *normal, const float *inst,
+                       const float *motion, float *o_color, float *o_moment, float *o_num, const float *h_color,
+                       const float *h_moment, const float *h_num, const float *h_normal, const float *h_inst);
+void orc_svgf_variance(int W, int H, const float *moment, const float *normal, const float *depth, const float *num,
+                       float *variance);
+void orc_svgf_spatial(int W, int H, int step, const float *color, const float *normal, const float *depth,
+                      const float *variance, float *out);
+void orc_taa(int W, int H, const float *color, const float *h_color, const float *motion, const float *normal,
+             const float *inst, const float *h_normal, const float *h_inst, float *out);
+
 #ifdef __cplusplus
 }
 #endif

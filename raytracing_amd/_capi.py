@@ -92,6 +92,10 @@ SIGNATURES = {
     "pt_post_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_post_static_blend": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_post_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_post_svgf_temporal": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 12),
+    "pt_post_svgf_variance": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "pt_post_svgf_spatial": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "pt_post_taa": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8),
     "pt_buf_save_as_image": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]),
     "pt_host_quantize_image": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pt_host_write_png": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -30,6 +30,7 @@ DEVICE_SOURCES = [
     "device/trace_kernels.hip",
     "device/path_kernels.hip",
     "device/post_kernels.hip",
+    "device/denoise_kernels.hip",
 ]
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result"]

@@ -1073,6 +1073,99 @@ int pt_post_tonemap(pt_ctx *ctx, const pt_buf *color, pt_buf *out) {
     return PT_OK;
 }
 
+// ------------------------------------------------------------------------------- denoising chain
+namespace {
+struct BufSpec { const pt_buf *b; int channels; const char *name; };
+// Common checks of the stencil passes: context, sizes, no output aliasing an input.
+int check_images(pt_ctx *ctx, const char *fn, int w, int h, std::initializer_list<BufSpec> in, std::initializer_list<BufSpec> out) {
+    if(!ctx) return fail(PT_ERR_INVALID, std::string(fn) + ": null context");
+    if(w <= 0 || h <= 0 || (long long)w * h > (1ll << 28)) return fail(PT_ERR_INVALID, std::string(fn) + ": unsupported resolution");
+    const size_t npix = (size_t)w * h;
+    for(const auto *list : {&in, &out})
+        for(const BufSpec &s : *list) {
+            if(!s.b) return fail(PT_ERR_INVALID, std::string(fn) + ": " + s.name + " is null");
+            if(s.b->ctx != ctx) return fail(PT_ERR_INVALID, std::string(fn) + ": " + s.name + " belongs to another context");
+            if(s.b->bytes != npix * s.channels * sizeof(float))
+                return fail(PT_ERR_INVALID, std::string(fn) + ": " + s.name + " must hold width*height*" + std::to_string(s.channels) + " floats");
+        }
+    for(const BufSpec &o : out)
+        for(const BufSpec &i : in)
+            if(o.b == i.b) return fail(PT_ERR_INVALID, std::string(fn) + ": " + o.name + " must not be the same buffer as " + i.name);
+    return PT_OK;
+}
+const float *fptr(const pt_buf *b) { return static_cast<const float *>(b->dptr); }
+float *fptr_out(pt_buf *b) {
+    b->version++;
+    b->shadow_valid = false;
+    return static_cast<float *>(b->dptr);
+}
+}  // namespace
+
+int pt_post_svgf_temporal(pt_ctx *ctx, int width, int height, int first_frame, const pt_buf *color, const pt_buf *normal,
+                          const pt_buf *instance_index, const pt_buf *motion, pt_buf *out_color, pt_buf *out_moment,
+                          pt_buf *out_num_samples, const pt_buf *history_color, const pt_buf *history_moment,
+                          const pt_buf *history_num_samples, const pt_buf *history_normal,
+                          const pt_buf *history_instance_index) {
+    int rc = check_images(ctx, "pt_post_svgf_temporal", width, height,
+                          {{color, 3, "color"}, {normal, 3, "normal"}, {instance_index, 1, "instance_index"}, {motion, 2, "motion"},
+                           {history_color, 3, "history_color"}, {history_moment, 2, "history_moment"},
+                           {history_num_samples, 1, "history_num_samples"}, {history_normal, 3, "history_normal"},
+                           {history_instance_index, 1, "history_instance_index"}},
+                          {{out_color, 3, "out_color"}, {out_moment, 2, "out_moment"}, {out_num_samples, 1, "out_num_samples"}});
+    if(rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    JOIN_TRY(ctx);
+    launch_svgf_temporal(ctx->stream, width, height, first_frame != 0, fptr(color), fptr(normal), fptr(instance_index), fptr(motion),
+                         fptr_out(out_color), fptr_out(out_moment), fptr_out(out_num_samples), fptr(history_color),
+                         fptr(history_moment), fptr(history_num_samples), fptr(history_normal), fptr(history_instance_index));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_post_svgf_variance(pt_ctx *ctx, int width, int height, const pt_buf *moment, const pt_buf *normal, const pt_buf *depth,
+                          const pt_buf *num_samples, pt_buf *out_variance) {
+    int rc = check_images(ctx, "pt_post_svgf_variance", width, height,
+                          {{moment, 2, "moment"}, {normal, 3, "normal"}, {depth, 1, "depth"}, {num_samples, 1, "num_samples"}},
+                          {{out_variance, 1, "out_variance"}});
+    if(rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    JOIN_TRY(ctx);
+    launch_svgf_variance(ctx->stream, width, height, fptr(moment), fptr(normal), fptr(depth), fptr(num_samples), fptr_out(out_variance));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_post_svgf_spatial(pt_ctx *ctx, int width, int height, int step, const pt_buf *color, const pt_buf *normal,
+                         const pt_buf *depth, const pt_buf *variance, pt_buf *out_color) {
+    int rc = check_images(ctx, "pt_post_svgf_spatial", width, height,
+                          {{color, 3, "color"}, {normal, 3, "normal"}, {depth, 1, "depth"}, {variance, 1, "variance"}},
+                          {{out_color, 3, "out_color"}});
+    if(rc) return rc;
+    if(step < 1) return fail(PT_ERR_INVALID, "pt_post_svgf_spatial: step must be at least 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    JOIN_TRY(ctx);
+    launch_svgf_spatial(ctx->stream, width, height, step, fptr(color), fptr(normal), fptr(depth), fptr(variance), fptr_out(out_color));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_post_taa(pt_ctx *ctx, int width, int height, const pt_buf *color, const pt_buf *history_color, const pt_buf *motion,
+                const pt_buf *normal, const pt_buf *instance_index, const pt_buf *history_normal,
+                const pt_buf *history_instance_index, pt_buf *out_color) {
+    int rc = check_images(ctx, "pt_post_taa", width, height,
+                          {{color, 3, "color"}, {history_color, 3, "history_color"}, {motion, 2, "motion"}, {normal, 3, "normal"},
+                           {instance_index, 1, "instance_index"}, {history_normal, 3, "history_normal"},
+                           {history_instance_index, 1, "history_instance_index"}},
+                          {{out_color, 3, "out_color"}});
+    if(rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    JOIN_TRY(ctx);
+    launch_taa(ctx->stream, width, height, fptr(color), fptr(history_color), fptr(motion), fptr(normal), fptr(instance_index),
+               fptr(history_normal), fptr(history_instance_index), fptr_out(out_color));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
 int pt_buf_save_as_image(const pt_buf *buf, int width, int height, int channel, const char *path) {
     if(!buf || !path) return fail(PT_ERR_INVALID, "pt_buf_save_as_image: null argument");
     if(width <= 0 || height <= 0 || (channel != 1 && channel != 3 && channel != 4))

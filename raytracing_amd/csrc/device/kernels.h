@@ -80,4 +80,15 @@ void launch_post_merge(hipStream_t s, int npix, const float *di, const float *id
 void launch_post_tonemap(hipStream_t s, size_t n, const float *in, float *out);
 void launch_post_static_blend(hipStream_t s, int npix, unsigned frame, const float *color, float *hist_color, float *hist_moment);
 
+// denoising chain (denoise_kernels.hip)
+void launch_svgf_temporal(hipStream_t s, int W, int H, int first_frame, const float *color, const float *normal, const float *inst,
+                          const float *motion, float *o_color, float *o_moment, float *o_num, const float *h_color,
+                          const float *h_moment, const float *h_num, const float *h_normal, const float *h_inst);
+void launch_svgf_variance(hipStream_t s, int W, int H, const float *moment, const float *normal, const float *depth,
+                          const float *num, float *variance);
+void launch_svgf_spatial(hipStream_t s, int W, int H, int step, const float *color, const float *normal, const float *depth,
+                         const float *variance, float *out);
+void launch_taa(hipStream_t s, int W, int H, const float *color, const float *h_color, const float *motion, const float *normal,
+                const float *inst, const float *h_normal, const float *h_inst, float *out);
+
 }  // namespace rta

@@ -113,6 +113,27 @@ def post_tonemap(ctx, color, out):
     check(lib.pt_post_tonemap(ctx.h, color.h, out.h))
 
 
+def post_svgf_temporal(ctx, w, h, first_frame, color, normal, instance_index, motion, out_color, out_moment, out_num_samples,
+                       history_color, history_moment, history_num_samples, history_normal, history_instance_index):
+    """One dispatch of SVGF_TemporalFilter.glsl (the history copies of SVGFTemporalFilter::draw are the caller's)."""
+    check(lib.pt_post_svgf_temporal(ctx.h, w, h, int(first_frame), color.h, normal.h, instance_index.h, motion.h, out_color.h,
+                                    out_moment.h, out_num_samples.h, history_color.h, history_moment.h, history_num_samples.h,
+                                    history_normal.h, history_instance_index.h))
+
+
+def post_svgf_variance(ctx, w, h, moment, normal, depth, num_samples, out_variance):
+    check(lib.pt_post_svgf_variance(ctx.h, w, h, moment.h, normal.h, depth.h, num_samples.h, out_variance.h))
+
+
+def post_svgf_spatial(ctx, w, h, step, color, normal, depth, variance, out_color):
+    check(lib.pt_post_svgf_spatial(ctx.h, w, h, int(step), color.h, normal.h, depth.h, variance.h, out_color.h))
+
+
+def post_taa(ctx, w, h, color, history_color, motion, normal, instance_index, history_normal, history_instance_index, out_color):
+    check(lib.pt_post_taa(ctx.h, w, h, color.h, history_color.h, motion.h, normal.h, instance_index.h, history_normal.h,
+                          history_instance_index.h, out_color.h))
+
+
 class Texture:
     def __init__(self, ctx, pixels):
         a = np.ascontiguousarray(pixels)
