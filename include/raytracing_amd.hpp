@@ -7,6 +7,7 @@
 //   SVGFMergePass        src/renderpass/SVGFMergePass.h:11-22
 //   StaticBlender        src/renderpass/StaticBlender.h
 //   ToneMappingGamma     src/renderpass/ToneMappingGamma.h
+//   SVGFTemporalFilter, SVGFVarianceFilter, SVGFSpatialFilterPass, TAA   src/renderpass/*.h
 //   ResourceManager      src/ResourceManager.h:80-90     the seven SSBO members + manager pointer
 //
 // What changes for a caller: GL object names become handles (pt_tex* instead of GLuint), and
@@ -20,6 +21,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "raytracing_amd.h"
@@ -312,6 +314,109 @@ public:
     ~ToneMappingGamma() override { outputColorGBufferSSBO.release(); }
     void draw(const SSBOBuffer<float> &colorGBufferSSBO) {
         check(pt_post_tonemap(Device::ctx(), colorGBufferSSBO.handle(), outputColorGBufferSSBO.handle()));
+    }
+};
+
+// Config::SVGFSpatialFilterLevel (src/Config.h:63): a-trous levels SVGFSpatialFilterPass::draw runs
+inline int &svgf_spatial_filter_level() { static int level = 0; return level; }
+
+class SVGFTemporalFilter : public RenderPass {  // src/renderpass/SVGFTemporalFilter.{h,cpp}
+public:
+    bool firstFrame = true;
+    SSBOBuffer<float> outputColorGBufferSSBO, outputMomentGBufferSSBO, outputNumSamplesGBufferSSBO;
+    SSBOBuffer<float> historyColorGBufferSSBO, historyMomentGBufferSSBO, historyNumSamplesGBufferSSBO,
+        historynormalGBufferSSBO, historyinstanceIndexGBufferSSBO;
+    SVGFTemporalFilter(const string &)
+        : outputColorGBufferSSBO((uint)(screen_w() * screen_h() * 3)), outputMomentGBufferSSBO((uint)(screen_w() * screen_h() * 2)),
+          outputNumSamplesGBufferSSBO((uint)(screen_w() * screen_h())), historyColorGBufferSSBO((uint)(screen_w() * screen_h() * 3)),
+          historyMomentGBufferSSBO((uint)(screen_w() * screen_h() * 2)), historyNumSamplesGBufferSSBO((uint)(screen_w() * screen_h())),
+          historynormalGBufferSSBO((uint)(screen_w() * screen_h() * 3)), historyinstanceIndexGBufferSSBO((uint)(screen_w() * screen_h())) {}
+    ~SVGFTemporalFilter() override {
+        for(SSBOBuffer<float> *b : {&outputColorGBufferSSBO, &outputMomentGBufferSSBO, &outputNumSamplesGBufferSSBO, &historyColorGBufferSSBO,
+                                    &historyMomentGBufferSSBO, &historyNumSamplesGBufferSSBO, &historynormalGBufferSSBO,
+                                    &historyinstanceIndexGBufferSSBO})
+            b->release();
+    }
+    void draw(const SSBOBuffer<float> &colorGBufferSSBO, const SSBOBuffer<float> &normalGBufferSSBO,
+              const SSBOBuffer<float> &instanceIndexGBufferSSBO, const SSBOBuffer<float> &motionGBufferSSBO) {
+        // as SVGFTemporalFilter.cpp:30-31: the flag is cleared BEFORE it is handed to the shader, so the
+        // shader's first-frame branch never runs and the first frame blends with whatever the history holds
+        if(firstFrame) firstFrame = false;
+        check(pt_post_svgf_temporal(Device::ctx(), screen_w(), screen_h(), firstFrame, colorGBufferSSBO.handle(),
+                                    normalGBufferSSBO.handle(), instanceIndexGBufferSSBO.handle(), motionGBufferSSBO.handle(),
+                                    outputColorGBufferSSBO.handle(), outputMomentGBufferSSBO.handle(), outputNumSamplesGBufferSSBO.handle(),
+                                    historyColorGBufferSSBO.handle(), historyMomentGBufferSSBO.handle(),
+                                    historyNumSamplesGBufferSSBO.handle(), historynormalGBufferSSBO.handle(),
+                                    historyinstanceIndexGBufferSSBO.handle()));
+        historyColorGBufferSSBO.copy(&outputColorGBufferSSBO);
+        historyMomentGBufferSSBO.copy(&outputMomentGBufferSSBO);
+        historyNumSamplesGBufferSSBO.copy(&outputNumSamplesGBufferSSBO);
+        historynormalGBufferSSBO.copy(&normalGBufferSSBO);
+        historyinstanceIndexGBufferSSBO.copy(&instanceIndexGBufferSSBO);
+    }
+    void update_historycolor(const SSBOBuffer<float> &colorGBufferSSBO) { historyColorGBufferSSBO.copy(&colorGBufferSSBO); }
+};
+
+class SVGFVarianceFilter : public RenderPass {  // src/renderpass/SVGFVarianceFilter.{h,cpp}
+public:
+    SSBOBuffer<float> varianceGBufferSSBO;
+    SVGFVarianceFilter(const string &) : varianceGBufferSSBO((uint)(screen_w() * screen_h())) {}
+    ~SVGFVarianceFilter() override { varianceGBufferSSBO.release(); }
+    void draw(const SSBOBuffer<float> &momentGBufferSSBO, const SSBOBuffer<float> &normalGBufferSSBO,
+              const SSBOBuffer<float> &depthGBufferSSBO, const SSBOBuffer<float> &numSamplesGBufferSSBO) {
+        check(pt_post_svgf_variance(Device::ctx(), screen_w(), screen_h(), momentGBufferSSBO.handle(), normalGBufferSSBO.handle(),
+                                    depthGBufferSSBO.handle(), numSamplesGBufferSSBO.handle(), varianceGBufferSSBO.handle()));
+    }
+};
+
+class SVGFSpatialFilterPass : public RenderPass {  // src/renderpass/SVGFSpatialFilterPass.{h,cpp}
+public:
+    SSBOBuffer<float> outputColorGBufferSSBO, tmpColorGBufferSSBO;
+    SVGFSpatialFilterPass(const string &)
+        : outputColorGBufferSSBO((uint)(screen_w() * screen_h() * 3)), tmpColorGBufferSSBO((uint)(screen_w() * screen_h() * 3)) {}
+    ~SVGFSpatialFilterPass() override {
+        outputColorGBufferSSBO.release();
+        tmpColorGBufferSSBO.release();
+    }
+    void draw(const SSBOBuffer<float> &colorGBufferSSBO, const SSBOBuffer<float> &varianceGBufferSSBO,
+              const SSBOBuffer<float> &normalGBufferSSBO, const SSBOBuffer<float> &depthGBufferSSBO) {
+        outputColorGBufferSSBO.copy(&colorGBufferSSBO);
+        for(int i = 0; i < svgf_spatial_filter_level(); i++) {
+            check(pt_post_svgf_spatial(Device::ctx(), screen_w(), screen_h(), 1 << i, outputColorGBufferSSBO.handle(),
+                                       normalGBufferSSBO.handle(), depthGBufferSSBO.handle(), varianceGBufferSSBO.handle(),
+                                       tmpColorGBufferSSBO.handle()));
+            std::swap(tmpColorGBufferSSBO, outputColorGBufferSSBO);
+        }
+    }
+};
+
+class TAA : public RenderPass {  // src/renderpass/TAA.{h,cpp}
+public:
+    bool firstFrame;
+    SSBOBuffer<float> historycolorGBufferSSBO, historynormalGBufferSSBO, historyinstanceIndexGBufferSSBO, outputColorGBufferSSBO;
+    TAA(const string &)
+        : firstFrame(true), historycolorGBufferSSBO((uint)(screen_w() * screen_h() * 3)),
+          historynormalGBufferSSBO((uint)(screen_w() * screen_h() * 3)), historyinstanceIndexGBufferSSBO((uint)(screen_w() * screen_h())),
+          outputColorGBufferSSBO((uint)(screen_w() * screen_h() * 3)) {}
+    ~TAA() override {
+        historycolorGBufferSSBO.release(); historynormalGBufferSSBO.release();
+        historyinstanceIndexGBufferSSBO.release(); outputColorGBufferSSBO.release();
+    }
+    void draw(const SSBOBuffer<float> &colorGBufferSSBO, const SSBOBuffer<float> &motionGBufferSSBO,
+              const SSBOBuffer<float> &normalGBufferSSBO, const SSBOBuffer<float> &instanceIndexGBufferSSBO) {
+        if(firstFrame) {  // TAA.cpp:19-25: the first frame only fills the history (outputColorGBufferSSBO keeps its content)
+            firstFrame = false;
+            historycolorGBufferSSBO.copy(&colorGBufferSSBO);
+            historynormalGBufferSSBO.copy(&normalGBufferSSBO);
+            historyinstanceIndexGBufferSSBO.copy(&instanceIndexGBufferSSBO);
+            return;
+        }
+        check(pt_post_taa(Device::ctx(), screen_w(), screen_h(), colorGBufferSSBO.handle(), historycolorGBufferSSBO.handle(),
+                          motionGBufferSSBO.handle(), normalGBufferSSBO.handle(), instanceIndexGBufferSSBO.handle(),
+                          historynormalGBufferSSBO.handle(), historyinstanceIndexGBufferSSBO.handle(), outputColorGBufferSSBO.handle()));
+        historycolorGBufferSSBO.copy(&outputColorGBufferSSBO);
+        historynormalGBufferSSBO.copy(&normalGBufferSSBO);
+        historyinstanceIndexGBufferSSBO.copy(&instanceIndexGBufferSSBO);
     }
 };
 

@@ -73,6 +73,26 @@ int main(int argc, char **argv) {
         StaticBlender *staticBlenderPass = new StaticBlender("shader/postprocessing/StaticBlender.glsl");
         ToneMappingGamma *mappingPass = new ToneMappingGamma("shader/postprocessing/ToneMappingGamma.glsl");
 
+        // the denoising branch of update() (main.cpp:213-300), on buffers of its own
+        svgf_spatial_filter_level() = 3;
+        SVGFTemporalFilter *svgfTemporalFilterPass[2] = {new SVGFTemporalFilter("shader/postprocessing/SVGF_TemporalFilter.glsl"),
+                                                         new SVGFTemporalFilter("shader/postprocessing/SVGF_TemporalFilter.glsl")};
+        SVGFVarianceFilter *svgfVarianceFilterPass[2] = {new SVGFVarianceFilter("shader/postprocessing/SVGF_VarianceFilter.glsl"),
+                                                         new SVGFVarianceFilter("shader/postprocessing/SVGF_VarianceFilter.glsl")};
+        SVGFSpatialFilterPass *svgfSpatialFilterPass[2] = {new SVGFSpatialFilterPass("shader/postprocessing/SVGF_SpatialFilter.glsl"),
+                                                           new SVGFSpatialFilterPass("shader/postprocessing/SVGF_SpatialFilter.glsl")};
+        SVGFMergePass *denoisedMergePass = new SVGFMergePass("shader/postprocessing/SVGF_Merge.glsl");
+        ToneMappingGamma *denoisedMappingPass = new ToneMappingGamma("shader/postprocessing/ToneMappingGamma.glsl");
+        TAA *taaPass = new TAA("shader/postprocessing/TAA.glsl");
+        // the reference leaves its history buffers uninitialised (glBufferData of new T[n]); zero them so that the
+        // first frame is defined
+        for(int k = 0; k < 2; k++) {
+            SVGFTemporalFilter *t = svgfTemporalFilterPass[k];
+            for(SSBOBuffer<float> *b : {&t->historyColorGBufferSSBO, &t->historyMomentGBufferSSBO, &t->historyNumSamplesGBufferSSBO,
+                                        &t->historynormalGBufferSSBO, &t->historyinstanceIndexGBufferSSBO})
+                b->fill(0.0f);
+        }
+
         auto pbytes = slurp(dir + "params.bin");  // SPP records of pt_params, the values update() would compute
         if(pbytes.size() != sizeof(pt_params) * (size_t)SPP) throw std::runtime_error("params.bin has the wrong size");
         const pt_params *P = reinterpret_cast<const pt_params *>(pbytes.data());
@@ -115,6 +135,34 @@ int main(int argc, char **argv) {
             targetTracer_rendered = &staticBlenderPass->historyColorGBufferSSBO;
             mappingPass->use();
             mappingPass->draw(*targetTracer_rendered);
+            {
+                SSBOBuffer<float> *targetTracer_directLum = &renderPass->directLumGBufferSSBO;
+                SSBOBuffer<float> *targetTracer_indirectLum = &renderPass->indirectLumGBufferSSBO;
+                SSBOBuffer<float> **targets[2] = {&targetTracer_directLum, &targetTracer_indirectLum};
+                for(int k = 0; k < 2; k++) {
+                    svgfTemporalFilterPass[k]->use();
+                    svgfTemporalFilterPass[k]->draw(**targets[k], renderPass->normalGBufferSSBO, renderPass->instanceIndexGBufferSSBO,
+                                                    renderPass->motionGBufferSSBO);
+                    svgfVarianceFilterPass[k]->use();
+                    svgfVarianceFilterPass[k]->draw(svgfTemporalFilterPass[k]->outputMomentGBufferSSBO, renderPass->normalGBufferSSBO,
+                                                    renderPass->depthGBufferSSBO, svgfTemporalFilterPass[k]->outputNumSamplesGBufferSSBO);
+                    svgfSpatialFilterPass[k]->use();
+                    svgfSpatialFilterPass[k]->draw(svgfTemporalFilterPass[k]->outputColorGBufferSSBO, svgfVarianceFilterPass[k]->varianceGBufferSSBO,
+                                                   renderPass->normalGBufferSSBO, renderPass->depthGBufferSSBO);
+                    *targets[k] = &svgfSpatialFilterPass[k]->outputColorGBufferSSBO;
+                    svgfTemporalFilterPass[k]->update_historycolor(**targets[k]);
+                }
+                denoisedMergePass->draw(*targetTracer_directLum, *targetTracer_indirectLum, renderPass->albedoGBufferSSBO);
+                denoisedMappingPass->draw(denoisedMergePass->colorGBufferSSBO);
+                taaPass->draw(denoisedMappingPass->outputColorGBufferSSBO, renderPass->motionGBufferSSBO, renderPass->normalGBufferSSBO,
+                              renderPass->instanceIndexGBufferSSBO);
+                if(frame == 2) {
+                    dump(dir + "out_svgf_di.bin", targetTracer_directLum->download());
+                    dump(dir + "out_svgf_idi.bin", targetTracer_indirectLum->download());
+                    dump(dir + "out_svgf_num.bin", svgfTemporalFilterPass[0]->outputNumSamplesGBufferSSBO.download());
+                    dump(dir + "out_taa.bin", taaPass->outputColorGBufferSSBO.download());
+                }
+            }
             if(frame == 1) {
                 dump(dir + "out_directLum_f1.bin", renderPass->directLumGBufferSSBO.download());
                 dump(dir + "out_color_f1.bin", svgfMergePass->colorGBufferSSBO.download());
@@ -146,6 +194,8 @@ int main(int argc, char **argv) {
         ok = ok && a.isempty();
         std::cout << (ok ? "ssbo_ok" : "ssbo_FAILED") << std::endl;
 
+        for(int k = 0; k < 2; k++) { delete svgfTemporalFilterPass[k]; delete svgfVarianceFilterPass[k]; delete svgfSpatialFilterPass[k]; }
+        delete taaPass; delete denoisedMappingPass; delete denoisedMergePass;
         delete mappingPass; delete staticBlenderPass; delete svgfMergePass; delete renderPass;
         for(pt_tex *t : textures) pt_tex_release(t);
         pt_tex_release(skyTex); pt_tex_release(cacheTex);

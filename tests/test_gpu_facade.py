@@ -50,12 +50,42 @@ def test_facade_frame_loop(casa, small_sky, oracle_mod, tmp_path):
 
     osc = oracle_mod.OracleScene(casa, small_sky)
     hist_c = np.zeros(w * h * 3, np.float32); hist_m = np.zeros(w * h * 2, np.float32)
+    n = w * h
+    z = lambda c: np.zeros(n * c, np.float32)
+    svgf = [dict(h_color=z(3), h_moment=z(2), h_num=z(1), h_normal=z(3), h_inst=z(1)) for _ in range(2)]
+    taa_hist = None
+
+    def denoise(acc):
+        nonlocal taa_hist
+        outs = []
+        for k, name in enumerate(("directLum", "indirectLum")):
+            H = svgf[k]
+            oc, om, on = oracle_mod.svgf_temporal(w, h, False, acc[name], acc["normal"], acc["instanceIndex"], acc["motion"],
+                                                  H["h_color"], H["h_moment"], H["h_num"], H["h_normal"], H["h_inst"])
+            var = oracle_mod.svgf_variance(w, h, om, acc["normal"], acc["depth"], on)
+            cur = oc
+            for lvl in range(3):
+                cur = oracle_mod.svgf_spatial(w, h, 1 << lvl, cur, acc["normal"], acc["depth"], var)
+            H.update(h_color=cur, h_moment=om, h_num=on, h_normal=acc["normal"].ravel().copy(), h_inst=acc["instanceIndex"].ravel().copy())
+            outs.append(cur)
+        ldr = oracle_mod.post_tonemap(oracle_mod.post_merge(outs[0], outs[1], acc["albedo"]))
+        if taa_hist is None:
+            out = None
+            taa_hist = dict(color=ldr)
+        else:
+            out = oracle_mod.taa(w, h, ldr, taa_hist["color"], acc["motion"], acc["normal"], acc["instanceIndex"], taa_hist["normal"], taa_hist["inst"])
+            taa_hist["color"] = out
+        taa_hist["normal"] = acc["normal"].ravel().copy()
+        taa_hist["inst"] = acc["instanceIndex"].ravel().copy()
+        return outs[0], outs[1], svgf[0]["h_num"], out
+
     for frame in (1, 2):
         acc = None
         for s in range(1, spp_n + 1):
             prm = scene.make_params(w, h, v2w, small_sky, spp=s, frame=frame, jitter=jit[s - 1], max_depth=depth,
                                     light_count=len(casa.lights))
             acc, _ = osc.render(prm, accum=acc)
+        svgf_di, svgf_idi, svgf_num, taa_out = denoise(acc)
         color = oracle_mod.post_merge(acc["directLum"], acc["indirectLum"], acc["albedo"])
         hist_c, hist_m = oracle_mod.post_static_blend(frame, color, hist_c, hist_m)
         if frame == 1:
@@ -67,3 +97,8 @@ def test_facade_frame_loop(casa, small_sky, oracle_mod, tmp_path):
     ldr = oracle_mod.post_tonemap(hist_c)
     assert bit_equal(np.fromfile(d + "/out_ldr.bin", np.float32), ldr)
     assert np.array_equal(decode_png(d + "/frame.png"), oracle_mod.quantize_image(ldr, w, h, 3))
+    # the denoising branch (SVGFTemporalFilter / SVGFVarianceFilter / SVGFSpatialFilterPass x2, merge, tone map, TAA), frame 2
+    assert bit_equal(np.fromfile(d + "/out_svgf_di.bin", np.float32), svgf_di)
+    assert bit_equal(np.fromfile(d + "/out_svgf_idi.bin", np.float32), svgf_idi)
+    assert bit_equal(np.fromfile(d + "/out_svgf_num.bin", np.float32), svgf_num)
+    assert bit_equal(np.fromfile(d + "/out_taa.bin", np.float32), taa_out)

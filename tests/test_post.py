@@ -108,3 +108,77 @@ def test_png_writer_roundtrip(tmp_path):
         assert np.array_equal(decode_png(path), px)
     assert _capi.lib.pt_host_write_png(b"/nonexistent_dir/x.png", 2, 2, 3, px.ctypes.data) != 0
     assert _capi.lib.pt_host_write_png(str(tmp_path / "bad.png").encode(), 2, 2, 2, px.ctypes.data) != 0
+
+
+# ---- denoising chain restatements (SVGF_*.glsl, TAA.glsl): properties that follow from the shader text
+
+def _fields(w, h, seed=0):
+    rng = np.random.default_rng(seed)
+    n = w * h
+    color = (rng.random((n, 3)) * 4).astype(np.float32)
+    normal = np.tile(np.array([[0.0, 0.6, 0.8]], np.float32), (n, 1))
+    inst = np.full(n, 2.0, np.float32)
+    depth = np.full(n, 12.0, np.float32)
+    return rng, n, color, normal, inst, depth
+
+
+def test_svgf_temporal_first_frame_and_static_history(oracle_mod):
+    w, h = 24, 13
+    rng, n, color, normal, inst, depth = _fields(w, h)
+    zero2 = np.zeros((n, 2), np.float32)
+    lum = (color[:, 0] * np.float32(0.212671) + color[:, 1] * np.float32(0.715160)) + color[:, 2] * np.float32(0.072169)
+    oc, om, on = oracle_mod.svgf_temporal(w, h, True, color, normal, inst, zero2, color * 0, zero2, inst * 0, normal, inst)
+    assert np.array_equal(oc.reshape(n, 3), color) and np.array_equal(om.reshape(n, 2)[:, 0], lum) and np.all(on == 1)
+    # static camera, same surface everywhere, history = a constant image close to every pixel's neighbourhood mean:
+    # accepted everywhere, blended 80/20, sample count incremented
+    flat = np.full((n, 3), 2.0, np.float32)
+    noisy = (flat + (rng.random((n, 3)) - 0.5).astype(np.float32) * 0.5).astype(np.float32)
+    h_num = np.full(n, 3.0, np.float32)
+    oc, om, on = oracle_mod.svgf_temporal(w, h, False, noisy, normal, inst, zero2, flat, zero2, h_num, normal, inst)
+    assert np.all(on == 4.0)
+    want = flat * (np.float32(1) - np.float32(0.2)) + noisy * np.float32(0.2)
+    assert np.max(np.abs(oc.reshape(n, 3) - want)) < 1e-6
+    # another instance in the history: rejected everywhere
+    oc, om, on = oracle_mod.svgf_temporal(w, h, False, noisy, normal, inst, zero2, flat, zero2, h_num, normal, inst + 1)
+    assert np.all(on == 1.0) and np.array_equal(oc.reshape(n, 3), noisy)
+    # motion that leaves the screen: restart
+    away = np.full((n, 2), 2.0, np.float32)
+    oc, om, on = oracle_mod.svgf_temporal(w, h, False, noisy, normal, inst, away, flat, zero2, h_num, normal, inst)
+    assert np.all(on == 1.0)
+
+
+def test_svgf_variance_and_spatial_on_flat_inputs(oracle_mod):
+    w, h = 20, 11
+    rng, n, color, normal, inst, depth = _fields(w, h, 1)
+    moment = np.stack([np.full(n, 3.0, np.float32), np.full(n, 11.5, np.float32)], 1)
+    for num in (1.0, 9.0):                                   # 7x7 edge-stopping and 3x3 blur branches
+        var = oracle_mod.svgf_variance(w, h, moment, normal, depth, np.full(n, num, np.float32))
+        assert np.allclose(var, 11.5 - 9.0, atol=1e-5)
+    # a constant image is a fixed point of the a-trous filter at every level; zero normals make every weight 0 -> (10000,0,0)
+    flat = np.full((n, 3), 0.75, np.float32)
+    for step in (1, 4):
+        out = oracle_mod.svgf_spatial(w, h, step, flat, normal, depth, np.full(n, 0.3, np.float32)).reshape(n, 3)
+        assert np.allclose(out, 0.75, atol=1e-6)
+    out = oracle_mod.svgf_spatial(w, h, 1, flat, normal * 0, depth, np.full(n, 0.3, np.float32)).reshape(n, 3)
+    assert np.all(out[:, 0] == 10000.0) and np.all(out[:, 1:] == 0.0)
+    # an edge in depth is kept: two half planes 40 apart do not bleed into each other
+    d2 = depth.copy().reshape(h, w); d2[:, w // 2:] += 40.0
+    img = np.zeros((h, w, 3), np.float32); img[:, w // 2:] = 1.0
+    out = oracle_mod.svgf_spatial(w, h, 1, img, normal, d2, np.full(n, 1.0, np.float32)).reshape(h, w, 3)
+    assert out[:, :w // 2].max() < 1e-6 and out[:, w // 2:].min() > 1 - 1e-6
+
+
+def test_taa_holds_a_static_image_and_clips_outliers(oracle_mod):
+    w, h = 18, 10
+    rng, n, color, normal, inst, depth = _fields(w, h, 2)
+    zero2 = np.zeros((n, 2), np.float32)
+    flat = np.full((n, 3), 0.4, np.float32)
+    out = oracle_mod.taa(w, h, flat, flat, zero2, normal, inst, normal, inst).reshape(n, 3)
+    assert np.allclose(out, 0.4, atol=1e-6)
+    # history far outside the neighbourhood's colour box is clipped onto it (sigma = 0 here): no ghost
+    out = oracle_mod.taa(w, h, flat, flat + 0.5, zero2, normal, inst, normal, inst).reshape(n, 3)
+    assert np.allclose(out, 0.4, atol=1e-5)
+    # different surface in the history: the current colour passes through
+    cur = (rng.random((n, 3))).astype(np.float32)
+    out = oracle_mod.taa(w, h, cur, flat, zero2, normal, inst, -normal, inst).reshape(n, 3)
+    assert np.array_equal(out, cur)
