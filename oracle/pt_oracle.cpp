@@ -1059,6 +1059,11 @@ void orc_quantize_image(const float *data, int w, int h, int c, uint8_t *out) {
 // ---------------------------------------------------------------- denoising chain
 namespace {
 inline float m_exp(float x) { return m_exp2(x * 1.44269504088896341f); }
+// pow(x, 128), x >= 0: seven squarings (well inside what GLSL allows for pow)
+inline float pow128(float x) {
+    for(int k = 0; k < 7; k++) x = x * x;
+    return x;
+}
 inline vec3 rd3(const float *b, long long ptr) { return vec3(b[ptr * 3 + 0], b[ptr * 3 + 1], b[ptr * 3 + 2]); }
 inline void wr3(float *b, long long ptr, vec3 v) { b[ptr * 3 + 0] = v.x; b[ptr * 3 + 1] = v.y; b[ptr * 3 + 2] = v.z; }
 inline float lumf(vec3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
@@ -1166,7 +1171,7 @@ void orc_svgf_variance(int W, int H, const float *momentB, const float *normalB,
                     long long ptr = (long long)iy * W + ix;
                     float w = k_atrous[std::abs(i)] * k_atrous[std::abs(j)];
                     if(reach == 3)
-                        w = w * m_pow(std::fmax(0.0f, dot(normal, rd3(normalB, ptr))), 128.0f) * m_exp(-std::fabs(depth - depthB[ptr]) / 2.0f);
+                        w = w * pow128(std::fmax(0.0f, dot(normal, rd3(normalB, ptr)))) * m_exp(-std::fabs(depth - depthB[ptr]) / 2.0f);
                     totalWeight += w;
                     rx += w * momentB[ptr * 2];
                     ry += w * momentB[ptr * 2 + 1];
@@ -1195,7 +1200,7 @@ void orc_svgf_spatial(int W, int H, int step, const float *colorB, const float *
                     vec3 diff = color - c2;
                     float len = std::sqrt(dot(diff, diff));
                     float w = k_atrous[std::abs(i)] * k_atrous[std::abs(j)] *
-                              m_pow(std::fmax(0.0f, dot(normal, rd3(normalB, ptr))), 128.0f) *
+                              pow128(std::fmax(0.0f, dot(normal, rd3(normalB, ptr)))) *
                               m_exp(-std::fabs(depth - depthB[ptr]) / 2.0f) *
                               m_exp(-std::fabs(len) / (sigma * 4.0f + 0.00001f));
                     totalWeight += w;
