@@ -121,7 +121,7 @@ struct pt_pass {
     AccelMeshLevel mesh_level;    // device arrays are cleared after upload; the two lookup tables stay
     AccelSceneLevel scene_level;  // header + max_stack (vectors are cleared after upload)
     uint64_t mesh_level_builds = 0, scene_level_builds = 0;
-    DeviceArray d_mesh_nodes, d_scene_nodes, d_tri_pos, d_tri_leaf, d_inst, d_spill, d_tex_table;
+    DeviceArray d_mesh_buf, d_scene_buf, d_spill, d_tex_table;  // the two traversal buffers (device_types.h)
     DeviceArray d_redo_isect;  // redo list of the ordered intersect
     int traversal_mode = 0;               // 0 ordered + exact fallback, 1 reference order only
     int n_textures = 0;
@@ -206,6 +206,18 @@ int upload_array(pt_ctx *ctx, DeviceArray &d, const void *src, size_t bytes) {
     return PT_OK;
 }
 
+// One device buffer from two host arrays laid end to end.
+int upload_pair(pt_ctx *ctx, DeviceArray &d, const void *a, size_t a_bytes, const void *b, size_t b_bytes) {
+    JOIN_TRY(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int rc = d.ensure(a_bytes + b_bytes);
+    if(rc) return rc;
+    if(a_bytes) HIP_TRY(hipMemcpyAsync(d.p, a, a_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if(b_bytes) HIP_TRY(hipMemcpyAsync(static_cast<char *>(d.p) + a_bytes, b, b_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
 bool slot_changed(pt_pass *p, int s) {
     return p->seen_ptr[s] != p->slots[s] || (p->slots[s] && p->seen_version[s] != p->slots[s]->version);
 }
@@ -260,11 +272,10 @@ int prepare_scene(pt_pass *p) {
                 AccelMeshLevel &ml = p->mesh_level;
                 if(!build_accel_mesh_level(mesh_n, n_mesh_nodes, reinterpret_cast<const TriangleRec *>(tris), b_tris->bytes / sizeof(TriangleRec), ml, err))
                     return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
-                if((rc = upload_array(ctx, p->d_mesh_nodes, ml.mesh_nodes.data(), ml.mesh_nodes.size() * sizeof(TNode)))) return rc;
-                if((rc = upload_array(ctx, p->d_tri_pos, ml.tri_pos.data(), ml.tri_pos.size() * sizeof(TriPos)))) return rc;
-                if((rc = upload_array(ctx, p->d_tri_leaf, ml.tri_leaf.data(), ml.tri_leaf.size() * sizeof(TLeaf)))) return rc;
+                if((rc = upload_pair(ctx, p->d_mesh_buf, ml.mesh_nodes.data(), ml.mesh_nodes.size() * sizeof(TNode), ml.tri_leaf.data(),
+                                     ml.tri_leaf.size() * sizeof(TLeaf))))
+                    return rc;
                 std::vector<TNode>().swap(ml.mesh_nodes);
-                std::vector<TriPos>().swap(ml.tri_pos);
                 std::vector<TLeaf>().swap(ml.tri_leaf);
                 p->mesh_level_valid = true;
                 p->mesh_level_builds++;
@@ -277,8 +288,9 @@ int prepare_scene(pt_pass *p) {
                 p->scene_level_valid = false;
                 return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
             }
-            if((rc = upload_array(ctx, p->d_scene_nodes, sl.scene_nodes.data(), sl.scene_nodes.size() * sizeof(TNode)))) return rc;
-            if((rc = upload_array(ctx, p->d_inst, sl.instances.data(), sl.instances.size() * sizeof(InstAccel)))) return rc;
+            if((rc = upload_pair(ctx, p->d_scene_buf, sl.scene_nodes.data(), sl.scene_nodes.size() * sizeof(TNode), sl.instances.data(),
+                                 sl.instances.size() * sizeof(InstAccel))))
+                return rc;
             p->scene_level.header = sl.header;
             p->scene_level.max_stack = sl.max_stack;
             int need = sl.max_stack + 2 - (LDS_STACK < FAST_LDS_STACK ? LDS_STACK : FAST_LDS_STACK);
@@ -331,10 +343,8 @@ int prepare_scene(pt_pass *p) {
 // spill == nullptr: the pass's own spill area (launches on the main stream)
 TraceScene make_trace_scene(pt_pass *p, void *spill = nullptr) {
     TraceScene sc;
-    sc.mesh_nodes = static_cast<const TNode *>(p->d_mesh_nodes.p);
-    sc.scene_nodes = static_cast<const TNode *>(p->d_scene_nodes.p);
-    sc.tri_pos = static_cast<const TriPos *>(p->d_tri_pos.p);
-    sc.inst = static_cast<const InstAccel *>(p->d_inst.p);
+    sc.mesh_buf = static_cast<const char *>(p->d_mesh_buf.p);
+    sc.scene_buf = static_cast<const char *>(p->d_scene_buf.p);
     sc.hdr = p->scene_level.header;
     sc.spill = static_cast<uint2 *>(spill ? spill : p->d_spill.p);
     sc.spill_depth = p->spill_depth;
@@ -394,10 +404,8 @@ void collect_profile(pt_pass *p) {
 
 FastScene make_fast_scene(pt_pass *p, void *spill = nullptr) {
     FastScene sc;
-    sc.mesh_nodes = static_cast<const TNode *>(p->d_mesh_nodes.p);
-    sc.scene_nodes = static_cast<const TNode *>(p->d_scene_nodes.p);
-    sc.tri_leaf = static_cast<const TLeaf *>(p->d_tri_leaf.p);
-    sc.inst = static_cast<const InstAccel *>(p->d_inst.p);
+    sc.mesh_buf = static_cast<const char *>(p->d_mesh_buf.p);
+    sc.scene_buf = static_cast<const char *>(p->d_scene_buf.p);
     sc.hdr = p->scene_level.header;
     sc.spill = static_cast<uint2 *>(spill ? spill : p->d_spill.p);
     sc.spill_depth = p->spill_depth;
@@ -700,7 +708,7 @@ int pt_pass_destroy(pt_pass *p) {
     collect_profile(p);
     for(hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
     for(pt_pass::Lane &l : p->lanes) release_lane(l);
-    DeviceArray *arrs[] = {&p->d_mesh_nodes, &p->d_scene_nodes, &p->d_tri_pos, &p->d_tri_leaf, &p->d_redo_isect, &p->d_inst,
+    DeviceArray *arrs[] = {&p->d_mesh_buf, &p->d_scene_buf, &p->d_redo_isect,
                            &p->d_spill, &p->d_tex_table, &p->d_counters, &p->d_stats, &p->d_err};
     for(DeviceArray *a : arrs) a->release();
     delete p;
@@ -787,7 +795,7 @@ int pt_pass_draw(pt_pass *p) {
     dp.materials = static_cast<const float *>(p->slots[PT_SLOT_MATERIAL]->dptr);
     dp.n_material_floats = (int)p->n_material_floats;
     dp.tris = static_cast<const TriangleRec *>(p->slots[PT_SLOT_TRIANGLE]->dptr);
-    dp.inst = static_cast<const InstAccel *>(p->d_inst.p);
+    dp.inst = reinterpret_cast<const InstAccel *>(static_cast<const char *>(p->d_scene_buf.p) + (size_t)p->scene_level.header.inst_base * 64);
     dp.lights = p->slots[PT_SLOT_LIGHT] ? static_cast<const LightInfo *>(p->slots[PT_SLOT_LIGHT]->dptr) : nullptr;
     dp.textures = static_cast<const TexDesc *>(p->d_tex_table.p);
     dp.n_textures = p->n_textures;

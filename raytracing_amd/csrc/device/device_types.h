@@ -11,12 +11,16 @@ namespace rta {
 // (half a 128-byte L2 line, four 16-byte loads per lane), and a child that is a leaf is
 // referenced directly, so leaves need no node fetch at all.
 //
-// Child reference: bits 31..30 = kind, bits 29..0 = index.
+// All traversal records are 64 bytes (an instance takes two) and live in two device buffers:
+//   mesh buffer   [ TNode x inner nodes of all meshes | TLeaf x triangles ]   follows slots 2 and 4
+//   scene buffer  [ TNode x scene inner nodes | InstAccel x instances ]       follows slots 3 and 5
+// so a step fetches base + 64 * slot whatever it is about to visit.
+// Child reference: bits 31..30 = kind, bits 29..0 = 64-byte slot in the kind's buffer.
 enum : uint32_t {
-    REF_MESH_INNER = 0u,   // index into the mesh TNode array
-    REF_TRIANGLE = 1u,     // index into the triangle arrays
-    REF_SCENE_INNER = 2u,  // index into the scene TNode array
-    REF_INSTANCE = 3u,     // index into the instance array
+    REF_MESH_INNER = 0u,   // mesh buffer, a TNode
+    REF_TRIANGLE = 1u,     // mesh buffer, a TLeaf: triangle index = slot - leaf_base
+    REF_SCENE_INNER = 2u,  // scene buffer, a TNode
+    REF_INSTANCE = 3u,     // scene buffer, an InstAccel: instance index = (slot - inst_base) / 2
     REF_INDEX_MASK = 0x3FFFFFFFu
 };
 inline uint32_t make_ref(uint32_t kind, uint32_t index) { return (kind << 30) | index; }
@@ -29,19 +33,10 @@ struct alignas(64) TNode {
 };
 static_assert(sizeof(TNode) == 64, "traversal node is 64 bytes");
 
-// Vertex 0 and the two edges (v1 - v0, v2 - v0) of a triangle, 48 bytes, 16-byte aligned.
-// The edges are the same fp32 differences the intersection routine would form itself.
-struct alignas(16) TriPos {
-    float v0[3];
-    float e1[3];
-    float e2[3];
-    float pad[3];
-};
-static_assert(sizeof(TriPos) == 48, "triangle position record is 48 bytes");
-
-// Triangle leaf of the ordered traversal, 64 bytes: the exact fp32 box of the leaf's PARENT
-// node in the reference tree (the last box the reference tests before it tests the
-// triangle; +-inf when the triangle is the whole mesh) followed by v0, e1, e2.
+// Triangle leaf, 64 bytes: the exact fp32 box of the leaf's PARENT node in the reference tree
+// (the last box the reference tests before it tests the triangle; +-inf when the triangle is
+// the whole mesh; read by the ordered traversal only) followed by vertex 0 and the two edges
+// v1 - v0, v2 - v0: the same fp32 differences the intersection routine would form itself.
 struct alignas(64) TLeaf {
     float parent_lo[3], parent_hi[3];
     float v0[3];
@@ -70,6 +65,8 @@ struct SceneHeader {
     uint32_t root_ref;             // scene inner node 0, or the only instance
     uint32_t n_instances;
     float extent;                  // |x| + |y| + |z| extent of the scene box (scales absolute tolerances)
+    uint32_t leaf_base;            // first TLeaf slot of the mesh buffer
+    uint32_t inst_base;            // first InstAccel slot of the scene buffer
 };
 
 // ---- closest-hit record (matches pt_hit in the public header, padded to 32 B in the

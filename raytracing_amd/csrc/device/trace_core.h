@@ -27,10 +27,8 @@ constexpr float RT_INF = 1e18f;
 constexpr float RT_RAY_MINDIS = 0.001f;
 
 struct TraceScene {
-    const TNode *mesh_nodes;
-    const TNode *scene_nodes;
-    const TriPos *tri_pos;
-    const InstAccel *inst;
+    const char *mesh_buf;    // TNodes of all meshes, then TLeafs (64-byte slots)
+    const char *scene_buf;   // scene TNodes, then InstAccels (two slots each)
     SceneHeader hdr;
     uint2 *spill;            // [spill_depth][total threads of the launch]
     int spill_depth;
@@ -187,11 +185,12 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
             const unsigned kind = ref >> 30, idx = ref & REF_INDEX_MASK;
             if(kind == REF_TRIANGLE) {
                 // intersect_triangle, shader/pathtracing.glsl:224-249 (Moller-Trumbore)
-                const float4 *tp = reinterpret_cast<const float4 *>(sc.tri_pos + idx);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                const float v0x = a.x, v0y = a.y, v0z = a.z;
-                const float e1x = a.w, e1y = b.x, e1z = b.y;
-                const float e2x = b.z, e2y = b.w, e2z = c.x;
+                // TLeaf: the parent box (not needed in this order), then v0, e1, e2 from float 6 on
+                const float4 *tp = reinterpret_cast<const float4 *>(sc.mesh_buf + ((size_t)idx << 6));
+                const float4 a = tp[1], b = tp[2], c = tp[3];
+                const float v0x = a.z, v0y = a.w, v0z = b.x;
+                const float e1x = b.y, e1y = b.z, e1z = b.w;
+                const float e2x = c.x, e2y = c.y, e2z = c.z;
                 const float sx = lox - v0x, sy = loy - v0y, sz = loz - v0z;
                 const float s1x = ldy * e2z - e2y * ldz, s1y = ldz * e2x - e2z * ldx, s1z = ldx * e2y - e2x * ldy;
                 const float s2x = sy * e1z - e1y * sz, s2y = sz * e1x - e1z * sx, s2z = sx * e1y - e1x * sy;
@@ -202,7 +201,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                 have = false;
                 if(RT_RAY_MINDIS <= t && 0.0f <= u && 0.0f <= v && u + v <= 1.0f && t < best.t) {
                     best.t = t; best.u = u; best.v = v;
-                    best.tri = (int)idx;
+                    best.tri = (int)(idx - sc.hdr.leaf_base);
                     best.inst = cur_inst;
                     if(any_hit) sp = 0;  // occlusion query: the first accepted hit decides
                 }
@@ -210,7 +209,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                 have = false;  // pruned when taken off the stack
             } else if(kind == REF_INSTANCE) {
                 // entry into intersect_meshBVH, shader/pathtracing.glsl:254-264
-                const float4 *ip = reinterpret_cast<const float4 *>(sc.inst + idx);
+                const float4 *ip = reinterpret_cast<const float4 *>(sc.scene_buf + ((size_t)idx << 6));
                 // rows, (root_ref, material), root box: lo.xyz hi.x | hi.yz ..
                 const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], rr = ip[3], bx0 = ip[4], bx1 = ip[5];
                 lox = (r0.x * wox + r0.y * woy) + (r0.z * woz + r0.w);
@@ -219,7 +218,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                 ldx = (r0.x * wdx + r0.y * wdy) + r0.z * wdz;
                 ldy = (r1.x * wdx + r1.y * wdy) + r1.z * wdz;
                 ldz = (r2.x * wdx + r2.y * wdy) + r2.z * wdz;
-                cur_inst = (int)idx;
+                cur_inst = (int)((idx - sc.hdr.inst_base) >> 1);
                 ref = __float_as_uint(rr.x);
                 if((ref >> 30) != REF_TRIANGLE) {
                     float t0;
@@ -228,7 +227,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                 }
             } else {
                 const bool mesh = kind == REF_MESH_INNER;
-                const float4 *np = reinterpret_cast<const float4 *>((mesh ? sc.mesh_nodes : sc.scene_nodes) + idx);
+                const float4 *np = reinterpret_cast<const float4 *>((mesh ? sc.mesh_buf : sc.scene_buf) + ((size_t)idx << 6));
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 const float rox = mesh ? lox : wox, roy = mesh ? loy : woy, roz = mesh ? loz : woz;
                 const float rdx = mesh ? ldx : wdx, rdy = mesh ? ldy : wdy, rdz = mesh ? ldz : wdz;

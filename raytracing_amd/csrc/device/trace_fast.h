@@ -42,10 +42,8 @@ constexpr int FAST_BLOCK = 256;
 constexpr int FAST_LDS_STACK = 8;  // 8-byte entries per lane in LDS: 16 KiB per block
 
 struct FastScene {
-    const TNode *mesh_nodes;
-    const TNode *scene_nodes;
-    const TLeaf *tri_leaf;
-    const InstAccel *inst;
+    const char *mesh_buf;    // TNodes of all meshes, then TLeafs (64-byte slots)
+    const char *scene_buf;   // scene TNodes, then InstAccels (two slots each)
     SceneHeader hdr;
     uint2 *spill;
     int spill_depth;
@@ -222,10 +220,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
             // ---- one 64-byte fetch per served lane, whatever the entry is
             float4 q0, q1, q2, q3;
             if(go) {
-                const char *base = kind == REF_MESH_INNER    ? reinterpret_cast<const char *>(sc.mesh_nodes + idx)
-                                   : kind == REF_TRIANGLE    ? reinterpret_cast<const char *>(sc.tri_leaf + idx)
-                                   : kind == REF_SCENE_INNER ? reinterpret_cast<const char *>(sc.scene_nodes + idx)
-                                                             : reinterpret_cast<const char *>(sc.inst + idx);
+                const char *base = ((kind & 2u) ? sc.scene_buf : sc.mesh_buf) + ((size_t)idx << 6);
                 const float4 *rp = reinterpret_cast<const float4 *>(base);
                 q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3];
             }  // (lanes that are not served leave q0..q3 unset and never read them)
@@ -302,7 +297,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 cdz = (q2.x * wdx + q2.y * wdy) + q2.z * wdz;
                 cix = fast_rcp(cdx); ciy = fast_rcp(cdy); ciz = fast_rcp(cdz);
                 in_mesh = true;
-                cur_inst = (int)idx;
+                cur_inst = (int)((idx - sc.hdr.inst_base) >> 1);
                 ref = __float_as_uint(q3.x);  // mesh root; its own box is implied by the boxes below it
             } else if(serve_leaf && is_leaf) {
                 // triangle leaf: q0, q1.xy parent box; then v0, e1, e2
@@ -331,7 +326,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                         if(pass) {
                             second_t = fminf(second_t, best.t);
                             best.t = t; best.u = u; best.v = v;
-                            best.tri = (int)idx;
+                            best.tri = (int)(idx - sc.hdr.leaf_base);
                             best.inst = cur_inst;
                             if(any_hit) sp = 0;
                         }

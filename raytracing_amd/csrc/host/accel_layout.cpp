@@ -53,11 +53,16 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
             inner_of[i] = n_inner++;
         }
     }
+    out.leaf_base = std::max<uint32_t>(n_inner, 1u);
+    if((uint64_t)out.leaf_base + n_tris >= REF_INDEX_MASK) {
+        err = "scene too large for 30-bit references";
+        return false;
+    }
     auto mesh_ref = [&](int32_t c) {
-        return mesh[c].triangleIndex >= 0 ? make_ref(REF_TRIANGLE, (uint32_t)mesh[c].triangleIndex)
+        return mesh[c].triangleIndex >= 0 ? make_ref(REF_TRIANGLE, out.leaf_base + (uint32_t)mesh[c].triangleIndex)
                                           : make_ref(REF_MESH_INNER, inner_of[c]);
     };
-    out.mesh_nodes.assign(std::max<size_t>(n_inner, 1), TNode());
+    out.mesh_nodes.assign(out.leaf_base, TNode());
     memset(out.mesh_nodes.data(), 0, out.mesh_nodes.size() * sizeof(TNode));
     out.height.assign(n_mesh_nodes, 1);
     for(size_t ii = n_mesh_nodes; ii-- > 0;) {
@@ -71,30 +76,18 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
         const int h = std::max<int>(out.height[p.lsIndex], out.height[p.rsIndex]) + 1;
         out.height[ii] = (uint8_t)std::min(h, 255);
     }
-    // ---- triangles
-    out.tri_pos.resize(n_tris);
-    for(size_t i = 0; i < n_tris; i++) {
-        const float *v = tris[i].ver;
-        TriPos &t = out.tri_pos[i];
-        for(int k = 0; k < 3; k++) {
-            t.v0[k] = v[k];
-            t.e1[k] = v[3 + k] - v[k];
-            t.e2[k] = v[6 + k] - v[k];
-            t.pad[k] = 0.0f;
-        }
-    }
-    // ---- ordered-traversal leaves: triangle + exact box of the reference parent node
+    // ---- leaves: triangle + exact box of the reference parent node
     out.tri_leaf.resize(n_tris);
     const float inf = std::numeric_limits<float>::infinity();
     for(size_t i = 0; i < n_tris; i++) {
         TLeaf &l = out.tri_leaf[i];
-        const TriPos &t = out.tri_pos[i];
+        const float *v = tris[i].ver;
         for(int k = 0; k < 3; k++) {
             l.parent_lo[k] = -inf;
             l.parent_hi[k] = inf;
-            l.v0[k] = t.v0[k];
-            l.e1[k] = t.e1[k];
-            l.e2[k] = t.e2[k];
+            l.v0[k] = v[k];
+            l.e1[k] = v[3 + k] - v[k];
+            l.e2[k] = v[6 + k] - v[k];
         }
         l.pad = 0.0f;
     }
@@ -130,7 +123,7 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
         return false;
     }
     auto mesh_ref = [&](int32_t c) {
-        return mesh[c].triangleIndex >= 0 ? make_ref(REF_TRIANGLE, (uint32_t)mesh[c].triangleIndex)
+        return mesh[c].triangleIndex >= 0 ? make_ref(REF_TRIANGLE, ml.leaf_base + (uint32_t)mesh[c].triangleIndex)
                                           : make_ref(REF_MESH_INNER, ml.inner_of[c]);
     };
     // ---- instances
@@ -175,11 +168,16 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
             sinner_of[i] = n_sinner++;
         }
     }
+    const uint32_t inst_base = std::max<uint32_t>(n_sinner, 1u);
+    if((uint64_t)inst_base + 2 * (uint64_t)n_inst >= REF_INDEX_MASK) {
+        err = "scene too large for 30-bit references";
+        return false;
+    }
     auto scene_ref = [&](int32_t c) {
-        return scene[c].instanceIndex >= 0 ? make_ref(REF_INSTANCE, (uint32_t)scene[c].instanceIndex)
+        return scene[c].instanceIndex >= 0 ? make_ref(REF_INSTANCE, inst_base + 2u * (uint32_t)scene[c].instanceIndex)
                                            : make_ref(REF_SCENE_INNER, sinner_of[c]);
     };
-    out.scene_nodes.assign(std::max<size_t>(n_sinner, 1), TNode());
+    out.scene_nodes.assign(inst_base, TNode());
     memset(out.scene_nodes.data(), 0, out.scene_nodes.size() * sizeof(TNode));
     std::vector<int> sheight(n_scene_nodes, 1);
     for(size_t ii = n_scene_nodes; ii-- > 0;) {
@@ -202,6 +200,8 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
     for(int k = 0; k < 3; k++) out.header.extent += std::fabs(scene[0].aa[k]) > std::fabs(scene[0].bb[k]) ? std::fabs(scene[0].aa[k]) : std::fabs(scene[0].bb[k]);
     out.header.root_ref = scene_ref(0);
     out.header.n_instances = (uint32_t)n_inst;
+    out.header.leaf_base = ml.leaf_base;
+    out.header.inst_base = inst_base;
     // each level of a walk defers at most one sibling
     out.max_stack = sheight[0] + max_mesh_height;
     return true;

@@ -12,9 +12,9 @@ namespace rta {
 
 // Mesh level: depends on the triangle and mesh-BVH buffers only.
 struct AccelMeshLevel {
-    std::vector<TNode> mesh_nodes;
-    std::vector<TriPos> tri_pos;
-    std::vector<TLeaf> tri_leaf;        // same index as tri_pos
+    std::vector<TNode> mesh_nodes;      // slots [0, leaf_base) of the mesh buffer
+    std::vector<TLeaf> tri_leaf;        // slots [leaf_base, leaf_base + n_tris)
+    uint32_t leaf_base = 0;
     // kept on the host for the scene level (instances name their mesh root by node index)
     std::vector<uint32_t> inner_of;     // reference node index -> index in mesh_nodes (inner nodes)
     std::vector<uint8_t> height;        // height of the subtree under each reference node, capped at 255
@@ -24,8 +24,8 @@ struct AccelMeshLevel {
 // Scene level: depends on the instance and scene-BVH buffers (and the mesh roots' boxes).
 // Small; rebuilt whenever instances move (the reference does that every frame, DynamicBVH).
 struct AccelSceneLevel {
-    std::vector<TNode> scene_nodes;
-    std::vector<InstAccel> instances;
+    std::vector<TNode> scene_nodes;     // slots [0, inst_base) of the scene buffer
+    std::vector<InstAccel> instances;   // two slots each from inst_base on
     SceneHeader header;
     int max_stack = 0;  // upper bound of deferred entries one ray can hold (scene + mesh height)
 };
