@@ -272,11 +272,8 @@ int prepare_scene(pt_pass *p) {
                 AccelMeshLevel &ml = p->mesh_level;
                 if(!build_accel_mesh_level(mesh_n, n_mesh_nodes, reinterpret_cast<const TriangleRec *>(tris), b_tris->bytes / sizeof(TriangleRec), ml, err))
                     return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
-                if((rc = upload_pair(ctx, p->d_mesh_buf, ml.mesh_nodes.data(), ml.mesh_nodes.size() * sizeof(TNode), ml.tri_leaf.data(),
-                                     ml.tri_leaf.size() * sizeof(TLeaf))))
-                    return rc;
-                std::vector<TNode>().swap(ml.mesh_nodes);
-                std::vector<TLeaf>().swap(ml.tri_leaf);
+                if((rc = upload_array(ctx, p->d_mesh_buf, ml.slots.data(), ml.slots.size() * sizeof(TNode)))) return rc;
+                std::vector<TNode>().swap(ml.slots);
                 p->mesh_level_valid = true;
                 p->mesh_level_builds++;
                 slot_mark(p, PT_SLOT_TRIANGLE);

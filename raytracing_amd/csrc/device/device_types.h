@@ -12,13 +12,14 @@ namespace rta {
 // referenced directly, so leaves need no node fetch at all.
 //
 // All traversal records are 64 bytes (an instance takes two) and live in two device buffers:
-//   mesh buffer   [ TNode x inner nodes of all meshes | TLeaf x triangles ]   follows slots 2 and 4
+//   mesh buffer   one slot per node of the reference's mesh BVHs, TNode (inner) or TLeaf (leaf),
+//                 each tree in depth-first order                            follows slots 2 and 4
 //   scene buffer  [ TNode x scene inner nodes | InstAccel x instances ]       follows slots 3 and 5
 // so a step fetches base + 64 * slot whatever it is about to visit.
 // Child reference: bits 31..30 = kind, bits 29..0 = 64-byte slot in the kind's buffer.
 enum : uint32_t {
     REF_MESH_INNER = 0u,   // mesh buffer, a TNode
-    REF_TRIANGLE = 1u,     // mesh buffer, a TLeaf: triangle index = slot - leaf_base
+    REF_TRIANGLE = 1u,     // mesh buffer, a TLeaf (which names its triangle)
     REF_SCENE_INNER = 2u,  // scene buffer, a TNode
     REF_INSTANCE = 3u,     // scene buffer, an InstAccel: instance index = (slot - inst_base) / 2
     REF_INDEX_MASK = 0x3FFFFFFFu
@@ -42,7 +43,7 @@ struct alignas(64) TLeaf {
     float v0[3];
     float e1[3];
     float e2[3];
-    float pad;
+    uint32_t triangle;  // index into the triangle buffer
 };
 static_assert(sizeof(TLeaf) == 64, "triangle leaf record is 64 bytes");
 
@@ -65,7 +66,6 @@ struct SceneHeader {
     uint32_t root_ref;             // scene inner node 0, or the only instance
     uint32_t n_instances;
     float extent;                  // |x| + |y| + |z| extent of the scene box (scales absolute tolerances)
-    uint32_t leaf_base;            // first TLeaf slot of the mesh buffer
     uint32_t inst_base;            // first InstAccel slot of the scene buffer
 };
 

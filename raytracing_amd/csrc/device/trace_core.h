@@ -27,7 +27,7 @@ constexpr float RT_INF = 1e18f;
 constexpr float RT_RAY_MINDIS = 0.001f;
 
 struct TraceScene {
-    const char *mesh_buf;    // TNodes of all meshes, then TLeafs (64-byte slots)
+    const char *mesh_buf;    // TNodes and TLeafs of all meshes (64-byte slots)
     const char *scene_buf;   // scene TNodes, then InstAccels (two slots each)
     SceneHeader hdr;
     uint2 *spill;            // [spill_depth][total threads of the launch]
@@ -201,7 +201,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                 have = false;
                 if(RT_RAY_MINDIS <= t && 0.0f <= u && 0.0f <= v && u + v <= 1.0f && t < best.t) {
                     best.t = t; best.u = u; best.v = v;
-                    best.tri = (int)(idx - sc.hdr.leaf_base);
+                    best.tri = __float_as_int(c.w);  // TLeaf::triangle
                     best.inst = cur_inst;
                     if(any_hit) sp = 0;  // occlusion query: the first accepted hit decides
                 }

@@ -42,7 +42,7 @@ constexpr int FAST_BLOCK = 256;
 constexpr int FAST_LDS_STACK = 8;  // 8-byte entries per lane in LDS: 16 KiB per block
 
 struct FastScene {
-    const char *mesh_buf;    // TNodes of all meshes, then TLeafs (64-byte slots)
+    const char *mesh_buf;    // TNodes and TLeafs of all meshes (64-byte slots)
     const char *scene_buf;   // scene TNodes, then InstAccels (two slots each)
     SceneHeader hdr;
     uint2 *spill;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                         if(pass) {
                             second_t = fminf(second_t, best.t);
                             best.t = t; best.u = u; best.v = v;
-                            best.tri = (int)(idx - sc.hdr.leaf_base);
+                            best.tri = __float_as_int(q3.w);  // TLeaf::triangle
                             best.inst = cur_inst;
                             if(any_hit) sp = 0;
                         }

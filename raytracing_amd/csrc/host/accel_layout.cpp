@@ -39,9 +39,7 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
         return false;
     }
     out.n_tris = n_tris;
-    std::vector<uint32_t> &inner_of = out.inner_of;
-    inner_of.assign(n_mesh_nodes, 0);
-    uint32_t n_inner = 0;
+    std::vector<uint8_t> has_parent(n_mesh_nodes, 0);
     for(size_t i = 0; i < n_mesh_nodes; i++) {
         if(mesh[i].triangleIndex >= 0) {
             if((size_t)mesh[i].triangleIndex >= n_tris) {
@@ -50,59 +48,67 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
             }
         } else {
             if(!check_children(mesh, n_mesh_nodes, i, "mesh", err)) return false;
-            inner_of[i] = n_inner++;
+            has_parent[mesh[i].lsIndex] = 1;
+            has_parent[mesh[i].rsIndex] = 1;
         }
     }
-    out.leaf_base = std::max<uint32_t>(n_inner, 1u);
-    if((uint64_t)out.leaf_base + n_tris >= REF_INDEX_MASK) {
-        err = "scene too large for 30-bit references";
-        return false;
+    // Slots: every reference node gets one 64-byte slot, inner nodes a TNode, leaves a TLeaf, in
+    // depth-first order of each tree (node, subtree of ls, subtree of rs): a walk down a tree
+    // moves through a shrinking address range, and a node often shares its 128-byte line with the
+    // child visited next.  (The reference numbers nodes breadth-first across all meshes.)
+    std::vector<uint32_t> &slot_of = out.slot_of;
+    slot_of.assign(n_mesh_nodes, 0xFFFFFFFFu);
+    uint32_t next = 0;
+    {
+        std::vector<int32_t> stack;
+        for(size_t r = 0; r < n_mesh_nodes; r++) {
+            if(has_parent[r]) continue;
+            stack.push_back((int32_t)r);
+            while(!stack.empty()) {
+                const int32_t n = stack.back();
+                stack.pop_back();
+                if(slot_of[n] != 0xFFFFFFFFu) continue;  // reached twice: the arrays form a DAG, keep the first slot
+                slot_of[n] = next++;
+                if(mesh[n].triangleIndex < 0) {
+                    stack.push_back(mesh[n].rsIndex);
+                    stack.push_back(mesh[n].lsIndex);
+                }
+            }
+        }
     }
-    auto mesh_ref = [&](int32_t c) {
-        return mesh[c].triangleIndex >= 0 ? make_ref(REF_TRIANGLE, out.leaf_base + (uint32_t)mesh[c].triangleIndex)
-                                          : make_ref(REF_MESH_INNER, inner_of[c]);
-    };
-    out.mesh_nodes.assign(out.leaf_base, TNode());
-    memset(out.mesh_nodes.data(), 0, out.mesh_nodes.size() * sizeof(TNode));
+    auto mesh_ref = [&](int32_t c) { return make_ref(mesh[c].triangleIndex >= 0 ? REF_TRIANGLE : REF_MESH_INNER, slot_of[c]); };
+    out.slots.assign(next, TNode());
+    memset(out.slots.data(), 0, out.slots.size() * sizeof(TNode));
     out.height.assign(n_mesh_nodes, 1);
-    for(size_t ii = n_mesh_nodes; ii-- > 0;) {
-        const BVHNodeInfo &p = mesh[ii];
-        if(p.triangleIndex >= 0) continue;
-        TNode &t = out.mesh_nodes[inner_of[ii]];
-        set_box(t.lo0, t.hi0, mesh[p.lsIndex]);
-        set_box(t.lo1, t.hi1, mesh[p.rsIndex]);
-        t.c0 = mesh_ref(p.lsIndex);
-        t.c1 = mesh_ref(p.rsIndex);
-        const int h = std::max<int>(out.height[p.lsIndex], out.height[p.rsIndex]) + 1;
-        out.height[ii] = (uint8_t)std::min(h, 255);
-    }
-    // ---- leaves: triangle + exact box of the reference parent node
-    out.tri_leaf.resize(n_tris);
     const float inf = std::numeric_limits<float>::infinity();
-    for(size_t i = 0; i < n_tris; i++) {
-        TLeaf &l = out.tri_leaf[i];
-        const float *v = tris[i].ver;
+    auto fill_leaf = [&](int32_t node, const float *plo, const float *phi) {
+        TLeaf &l = *reinterpret_cast<TLeaf *>(&out.slots[slot_of[node]]);
+        const float *v = tris[mesh[node].triangleIndex].ver;
         for(int k = 0; k < 3; k++) {
-            l.parent_lo[k] = -inf;
-            l.parent_hi[k] = inf;
+            l.parent_lo[k] = plo ? plo[k] : -inf;
+            l.parent_hi[k] = phi ? phi[k] : inf;
             l.v0[k] = v[k];
             l.e1[k] = v[3 + k] - v[k];
             l.e2[k] = v[6 + k] - v[k];
         }
-        l.pad = 0.0f;
-    }
-    for(size_t ii = 0; ii < n_mesh_nodes; ii++) {
+        l.triangle = (uint32_t)mesh[node].triangleIndex;
+    };
+    for(size_t ii = n_mesh_nodes; ii-- > 0;) {
         const BVHNodeInfo &p = mesh[ii];
-        if(p.triangleIndex >= 0) continue;
-        const int32_t kids[2] = {p.lsIndex, p.rsIndex};
-        for(int32_t c : kids)
-            if(mesh[c].triangleIndex >= 0) {
-                TLeaf &l = out.tri_leaf[mesh[c].triangleIndex];
-                for(int k = 0; k < 3; k++) {
-                    l.parent_lo[k] = p.aa[k];
-                    l.parent_hi[k] = p.bb[k];
-                }
-            }
+        if(p.triangleIndex >= 0) {
+            if(!has_parent[ii]) fill_leaf((int32_t)ii, nullptr, nullptr);  // a one-triangle mesh
+            continue;
+        }
+        TNode &t = out.slots[slot_of[ii]];
+        set_box(t.lo0, t.hi0, mesh[p.lsIndex]);
+        set_box(t.lo1, t.hi1, mesh[p.rsIndex]);
+        t.c0 = mesh_ref(p.lsIndex);
+        t.c1 = mesh_ref(p.rsIndex);
+        // a leaf carries the exact box of its parent in the reference tree
+        for(int32_t c : {p.lsIndex, p.rsIndex})
+            if(mesh[c].triangleIndex >= 0) fill_leaf(c, p.aa, p.bb);
+        const int h = std::max<int>(out.height[p.lsIndex], out.height[p.rsIndex]) + 1;
+        out.height[ii] = (uint8_t)std::min(h, 255);
     }
     return true;
 }
@@ -118,14 +124,11 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
         err = "scene too large for 30-bit references";
         return false;
     }
-    if(ml.inner_of.size() != n_mesh_nodes) {
+    if(ml.slot_of.size() != n_mesh_nodes) {
         err = "mesh level was built for another mesh BVH";
         return false;
     }
-    auto mesh_ref = [&](int32_t c) {
-        return mesh[c].triangleIndex >= 0 ? make_ref(REF_TRIANGLE, ml.leaf_base + (uint32_t)mesh[c].triangleIndex)
-                                          : make_ref(REF_MESH_INNER, ml.inner_of[c]);
-    };
+    auto mesh_ref = [&](int32_t c) { return make_ref(mesh[c].triangleIndex >= 0 ? REF_TRIANGLE : REF_MESH_INNER, ml.slot_of[c]); };
     // ---- instances
     out.instances.resize(n_inst);
     int max_mesh_height = 1;
@@ -200,7 +203,6 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
     for(int k = 0; k < 3; k++) out.header.extent += std::fabs(scene[0].aa[k]) > std::fabs(scene[0].bb[k]) ? std::fabs(scene[0].aa[k]) : std::fabs(scene[0].bb[k]);
     out.header.root_ref = scene_ref(0);
     out.header.n_instances = (uint32_t)n_inst;
-    out.header.leaf_base = ml.leaf_base;
     out.header.inst_base = inst_base;
     // each level of a walk defers at most one sibling
     out.max_stack = sheight[0] + max_mesh_height;

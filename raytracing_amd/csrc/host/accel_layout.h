@@ -12,11 +12,9 @@ namespace rta {
 
 // Mesh level: depends on the triangle and mesh-BVH buffers only.
 struct AccelMeshLevel {
-    std::vector<TNode> mesh_nodes;      // slots [0, leaf_base) of the mesh buffer
-    std::vector<TLeaf> tri_leaf;        // slots [leaf_base, leaf_base + n_tris)
-    uint32_t leaf_base = 0;
+    std::vector<TNode> slots;           // the mesh buffer: one 64-byte slot per reference node, TNode or TLeaf
     // kept on the host for the scene level (instances name their mesh root by node index)
-    std::vector<uint32_t> inner_of;     // reference node index -> index in mesh_nodes (inner nodes)
+    std::vector<uint32_t> slot_of;      // reference node index -> slot
     std::vector<uint8_t> height;        // height of the subtree under each reference node, capped at 255
     size_t n_tris = 0;
 };
