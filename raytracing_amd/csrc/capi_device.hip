@@ -433,8 +433,13 @@ void release_lane(pt_pass::Lane &l) {
 }
 
 // Stream, events and path state of one lane, sized for the pass and the scene bound now.
+// path-state slots of a w x h image: whole tiles of 64 pixels
+size_t state_slots(int w, int h) {
+    return (size_t)((w + STATE_TILE_W - 1) / STATE_TILE_W) * (size_t)((h + STATE_TILE_H - 1) / STATE_TILE_H) * 64u;
+}
+
 int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow) {
-    const size_t npix = (size_t)p->W * p->H;
+    const size_t npix = state_slots(p->W, p->H);
     if(!l.stream) {
         HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         for(hipEvent_t *e : {&l.done, &l.gbuf, &l.fin, &l.start}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -777,7 +782,7 @@ int pt_pass_draw(pt_pass *p) {
         if(!lb || lb->bytes < (size_t)P.lightCount * sizeof(LightInfo))
             return fail(PT_ERR_STATE, "pt_pass_draw: lightCount exceeds the bound light buffer");
     }
-    const size_t npix = (size_t)p->W * p->H;
+    const size_t npix = state_slots(p->W, p->H);
     const int n_shadow = 1 + P.lightCount;
     pt_pass::Lane &L = p->lanes[p->next_lane];
     p->next_lane = (p->next_lane + 1) % p->n_lanes;
@@ -788,6 +793,7 @@ int pt_pass_draw(pt_pass *p) {
     dp.p = P;
     dp.tan_half_fov = std::tan(P.fov / 2.0f);
     dp.W = p->W; dp.H = p->H; dp.npix = (int)npix;
+    dp.tiles_x = (p->W + STATE_TILE_W - 1) / STATE_TILE_W;
     dp.n_shadow = n_shadow;
     dp.materials = static_cast<const float *>(p->slots[PT_SLOT_MATERIAL]->dptr);
     dp.n_material_floats = (int)p->n_material_floats;

@@ -8,11 +8,23 @@
 
 namespace rta {
 
+// Path state is kept per slot, and slots are numbered tile by tile (STATE_TILE_W x STATE_TILE_H
+// pixels, 64 slots = one wavefront): the rays of one wavefront start from a square patch of the
+// image rather than a 64-pixel strip, so they visit more of the same nodes.  The outputs stay in
+// row-major pixel order.  Slots of a tile that hang over the right or bottom edge name no pixel.
+#ifndef STATE_TILE_W
+#define STATE_TILE_W 8
+#endif
+constexpr int STATE_TILE_H = 64 / STATE_TILE_W;
+static_assert(STATE_TILE_W * STATE_TILE_H == 64, "a tile is one wavefront");
+
 // Everything one draw needs, passed to the kernels by value.
 struct DrawParams {
     pt_params p;
     float tan_half_fov;  // tan(fov / 2), evaluated once on the host
-    int W, H, npix;
+    int W, H;
+    int npix;     // path-state slots: whole tiles, so >= W * H (see state_pixel)
+    int tiles_x;  // tiles per row
     int n_shadow;  // shadow entries per pixel = 1 (sky) + lightCount
     // scene
     const float *materials;

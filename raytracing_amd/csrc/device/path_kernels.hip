@@ -48,12 +48,28 @@ __device__ __forceinline__ void camera_ray(const pt_params &p, float tan_half_fo
     dir = normalize(d);
 }
 
+// slot -> pixel; false for the slots of an edge tile that lie outside the image
+__device__ __forceinline__ bool state_pixel(const DrawParams &dp, unsigned i, unsigned &px, unsigned &py) {
+    const unsigned tile = i >> 6, in = i & 63u;
+    const unsigned ty = tile / (unsigned)dp.tiles_x, tx = tile - ty * (unsigned)dp.tiles_x;
+    px = tx * STATE_TILE_W + in % STATE_TILE_W;
+    py = ty * STATE_TILE_H + in / STATE_TILE_W;
+    return px < (unsigned)dp.W && py < (unsigned)dp.H;
+}
+
 __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
     const unsigned nthreads = gridDim.x * blockDim.x;
     for(unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)dp.npix; i += nthreads) {
-        const unsigned px = i % (unsigned)dp.W, py = i / (unsigned)dp.W;
+        unsigned px, py;
         V3 o, d;
-        camera_ray(dp.p, dp.tan_half_fov, px, py, o, d);
+        if(state_pixel(dp, i, px, py)) {
+            camera_ray(dp.p, dp.tan_half_fov, px, py, o, d);
+        } else {
+            // no pixel: a ray with a NaN direction ends as a miss without any traversal, and
+            // shade() drops the slot
+            o = v3(0.0f);
+            d = v3(__uint_as_float(0x7FC00000u));
+        }
         float4 *r = reinterpret_cast<float4 *>(dp.rays + i);
         r[0] = make_float4(o.x, o.y, o.z, 0.0f);
         r[1] = make_float4(d.x, d.y, d.z, 0.0f);
@@ -66,9 +82,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
         a[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if(blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&dp.stats[0], (unsigned long long)dp.npix);
+        atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H);
         atomicAdd(&dp.stats[3], 1ull);
-        dp.counters[0] = (unsigned)dp.npix;  // every pixel is in the first queue
+        dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
     }
 }
 
@@ -94,13 +110,15 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
 
     if(blockIdx.x == 0 && threadIdx.x == 0) {
         // (with RasterizaionFor1st the first vertex comes from images: no rays were traced for it)
-        if(!RASTER_FIRST) atomicAdd(&dp.stats[1], (unsigned long long)n);
+        if(!RASTER_FIRST) atomicAdd(&dp.stats[1], dep == 0 ? (unsigned long long)dp.W * (unsigned long long)dp.H : (unsigned long long)n);
         if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
     }
 
     for(unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += nthreads) {
         const unsigned i = queue_in ? queue_in[q] : q;
-        const unsigned px = i % (unsigned)dp.W, py = i / (unsigned)dp.W;
+        unsigned px, py;
+        if(!state_pixel(dp, i, px, py)) continue;
+        const size_t pix = (size_t)py * (unsigned)dp.W + px;  // index into the outputs
 
         const float4 *rp = reinterpret_cast<const float4 *>(dp.rays + i);
         const float4 r0 = rp[0], r1 = rp[1];
@@ -170,13 +188,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
                 const float ny = (bp[1] * mp.x + bp[5] * mp.y) + (bp[9] * mp.z + bp[13]);
                 const float nw = (bp[3] * mp.x + bp[7] * mp.y) + (bp[11] * mp.z + bp[15]);
                 const float suv_x = ((float)px + 0.5f) / (float)dp.W, suv_y = ((float)py + 0.5f) / (float)dp.H;
-                dp.o_motion[(size_t)i * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
-                dp.o_motion[(size_t)i * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
-                dp.o_depth[i] = raster0 ? hit_t : 1000000.0f;
-                dp.o_normal[(size_t)i * 3] = g_normal.x;
-                dp.o_normal[(size_t)i * 3 + 1] = g_normal.y;
-                dp.o_normal[(size_t)i * 3 + 2] = g_normal.z;
-                dp.o_inst[i] = raster0 ? (float)hit_inst : -1.0f;
+                dp.o_motion[pix * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
+                dp.o_motion[pix * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
+                dp.o_depth[pix] = raster0 ? hit_t : 1000000.0f;
+                dp.o_normal[pix * 3] = g_normal.x;
+                dp.o_normal[pix * 3 + 1] = g_normal.y;
+                dp.o_normal[pix * 3 + 2] = g_normal.z;
+                dp.o_inst[pix] = raster0 ? (float)hit_inst : -1.0f;
                 continue;
             }
         } else {
@@ -229,13 +247,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int d
             const float ny = (bp[1] * position.x + bp[5] * position.y) + (bp[9] * position.z + bp[13]);
             const float nw = (bp[3] * position.x + bp[7] * position.y) + (bp[11] * position.z + bp[15]);
             const float suv_x = ((float)px + 0.5f) / (float)dp.W, suv_y = ((float)py + 0.5f) / (float)dp.H;
-            dp.o_motion[(size_t)i * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
-            dp.o_motion[(size_t)i * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
-            dp.o_depth[i] = hit_t;
-            dp.o_normal[(size_t)i * 3] = normal.x;
-            dp.o_normal[(size_t)i * 3 + 1] = normal.y;
-            dp.o_normal[(size_t)i * 3 + 2] = normal.z;
-            dp.o_inst[i] = (float)hit_inst;
+            dp.o_motion[pix * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
+            dp.o_motion[pix * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
+            dp.o_depth[pix] = hit_t;
+            dp.o_normal[pix * 3] = normal.x;
+            dp.o_normal[pix * 3 + 1] = normal.y;
+            dp.o_normal[pix * 3 + 2] = normal.z;
+            dp.o_inst[pix] = (float)hit_inst;
             if(dep >= P.MAX_DEPTH) continue;
         }
 
@@ -354,6 +372,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void finalize_kernel(DrawParams dp) {
     const pt_params &P = dp.p;
     const unsigned nthreads = gridDim.x * blockDim.x;
     for(unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)dp.npix; i += nthreads) {
+        unsigned px, py;
+        if(!state_pixel(dp, i, px, py)) continue;
         const float4 *a = reinterpret_cast<const float4 *>(dp.acc + i);
         const float4 a0 = a[0], a1 = a[1], a2 = a[2];
         V3 resultDI = v3(a0.x, a0.y, a0.z), resultGI = v3(a1.x, a1.y, a1.z);
@@ -364,7 +384,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void finalize_kernel(DrawParams dp) {
         V3 albedo = first_exist ? v3(a2.x, a2.y, a2.z) : resultGI;
         resultDI = resultDI / vmax(v3(S_EPS), albedo);
         resultIDI = resultIDI / vmax(v3(S_EPS), albedo);
-        const size_t o3 = (size_t)i * 3;
+        const size_t o3 = ((size_t)py * (unsigned)dp.W + px) * 3;
         if(P.currentspp != 1u) {
             const V3 lastdi = v3(dp.o_direct[o3], dp.o_direct[o3 + 1], dp.o_direct[o3 + 2]);
             const V3 lastidi = v3(dp.o_indirect[o3], dp.o_indirect[o3 + 1], dp.o_indirect[o3 + 2]);
