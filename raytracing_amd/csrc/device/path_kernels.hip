@@ -96,8 +96,13 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 
 // RASTER_FIRST: the instance launched for vertex 0 when the first hit comes from the raster images;
 // kept apart so that the common instance carries none of its registers.
+// Four waves per SIMD (128 registers, a few of them spilled) hide the latency of the gathers
+// better than the three the kernel would get unconstrained (145 registers); five spill too much.
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 4
+#endif
 template <bool RASTER_FIRST>
-__global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(DrawParams dp, int dep, const unsigned *queue_in,
+__global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES, SHADE_WAVES))) void shade_kernel(DrawParams dp, int dep, const unsigned *queue_in,
                                                             const unsigned *count_in, unsigned *queue_out,
                                                             unsigned *count_out, unsigned *shadow_queue,
                                                             unsigned *shadow_count) {
