@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--texture-size", type=int, default=4096)
     ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
     ap.add_argument("--pipeline", type=int, default=6, help="draws in flight on the device (pt_pass_set_pipeline)")
+    ap.add_argument("--wide-nodes", type=int, default=-1, choices=[-1, 0, 1],
+                    help="node format of the ordered traversal (pt_pass_set_wide_nodes): -1 library default, 0 fp32, 1 quantised")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank control flow on ONE GPU: all ranks use device 0, gloo backend, collectives staged through the host")
     ap.add_argument("--dump", default=None, help="rank 0 writes the final output buffers to this .npz")
@@ -122,6 +124,7 @@ def main():
     npix = W * H
     p = device.PathTracingPass(ctx, W if wl != "casa_isect" else 16, H if wl != "casa_isect" else 16)
     p.bind_scene(sb)
+    p.set_wide_nodes(args.wide_nodes)
     _r = device.Buffer(ctx, np.array([0, 0, 0, 0, 0, 1], np.float32))
     _h = device.Buffer(ctx, nbytes=device.HIT_DTYPE.itemsize)
     p.intersect(_r, 1, _h)

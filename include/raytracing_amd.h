@@ -181,6 +181,13 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
  *   1 the reference's visiting order for every ray (shader/pathtracing.glsl:254-316). */
 int pt_pass_set_traversal(pt_pass *pass, int mode);
 
+/* Node format of the ordered traversal; no counterpart in the reference, results do not depend
+ * on it.  The ordered traversal walks the reference's binary trees collapsed to four children
+ * per node:  0 = 128-byte nodes with the reference's fp32 boxes,  1 = 64-byte nodes with boxes
+ * on a 256-step grid rounded outwards (half the bytes and loads per visit; faster on every
+ * scene measured),  -1 (default) = the library's choice, currently 1. */
+int pt_pass_set_wide_nodes(pt_pass *pass, int format);
+
 /* How many draws may be in flight on the device at once (1..16, default 3); no counterpart in
  * the reference, whose GL driver queues frames by itself.  pt_pass_draw returns as soon as
  * the draw is queued; consecutive draws run on separate HIP streams with path state of their

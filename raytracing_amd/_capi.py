@@ -88,6 +88,7 @@ SIGNATURES = {
     "pt_pass_output": (C.c_int, [C.c_void_p, C.c_int, c_void_pp]),
     "pt_pass_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats), C.c_int]),
     "pt_pass_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_pass_set_wide_nodes": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_post_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_post_static_blend": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -124,6 +124,7 @@ struct pt_pass {
     DeviceArray d_mesh_buf, d_scene_buf, d_spill, d_tex_table;  // the two traversal buffers (device_types.h)
     DeviceArray d_redo_isect;  // redo list of the ordered intersect
     int traversal_mode = 0;               // 0 ordered + exact fallback, 1 reference order only
+    int quantise = -1;                    // wide nodes: -1 by scene size, 0 WNodes, 1 QNodes
     int n_textures = 0;
     int spill_depth = 0;
     size_t n_material_floats = 0;
@@ -206,18 +207,6 @@ int upload_array(pt_ctx *ctx, DeviceArray &d, const void *src, size_t bytes) {
     return PT_OK;
 }
 
-// One device buffer from two host arrays laid end to end.
-int upload_pair(pt_ctx *ctx, DeviceArray &d, const void *a, size_t a_bytes, const void *b, size_t b_bytes) {
-    JOIN_TRY(ctx);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    int rc = d.ensure(a_bytes + b_bytes);
-    if(rc) return rc;
-    if(a_bytes) HIP_TRY(hipMemcpyAsync(d.p, a, a_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if(b_bytes) HIP_TRY(hipMemcpyAsync(static_cast<char *>(d.p) + a_bytes, b, b_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return PT_OK;
-}
-
 bool slot_changed(pt_pass *p, int s) {
     return p->seen_ptr[s] != p->slots[s] || (p->slots[s] && p->seen_version[s] != p->slots[s]->version);
 }
@@ -270,7 +259,7 @@ int prepare_scene(pt_pass *p) {
                 p->mesh_level_valid = false;
                 p->scene_level_valid = false;
                 AccelMeshLevel &ml = p->mesh_level;
-                if(!build_accel_mesh_level(mesh_n, n_mesh_nodes, reinterpret_cast<const TriangleRec *>(tris), b_tris->bytes / sizeof(TriangleRec), ml, err))
+                if(!build_accel_mesh_level(mesh_n, n_mesh_nodes, reinterpret_cast<const TriangleRec *>(tris), b_tris->bytes / sizeof(TriangleRec), {}, p->quantise, ml, err))
                     return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
                 if((rc = upload_array(ctx, p->d_mesh_buf, ml.slots.data(), ml.slots.size() * sizeof(TNode)))) return rc;
                 std::vector<TNode>().swap(ml.slots);
@@ -280,14 +269,40 @@ int prepare_scene(pt_pass *p) {
                 slot_mark(p, PT_SLOT_MESH_BVH);
             }
             AccelSceneLevel sl;
-            if(!build_accel_scene_level(mesh_n, n_mesh_nodes, p->mesh_level, reinterpret_cast<const BVHNodeInfo *>(scene),
-                                        b_scene->bytes / sizeof(BVHNodeInfo), ii, n_inst, sl, err)) {
+            bool missing_root = false;
+            bool ok = build_accel_scene_level(mesh_n, n_mesh_nodes, p->mesh_level, reinterpret_cast<const BVHNodeInfo *>(scene),
+                                              b_scene->bytes / sizeof(BVHNodeInfo), ii, n_inst, sl, err, &missing_root);
+            if(!ok && missing_root) {
+                // an instance starts inside a tree: give the mesh level wide trees for those nodes too
+                std::vector<int32_t> roots;
+                for(size_t i = 0; i < n_inst; i++) roots.push_back(ii[i].meshIndex);
+                if((rc = host_view(b_tris, t_tris, &tris))) return rc;
+                p->mesh_level_valid = false;
+                AccelMeshLevel &ml = p->mesh_level;
+                if(!build_accel_mesh_level(mesh_n, n_mesh_nodes, reinterpret_cast<const TriangleRec *>(tris), b_tris->bytes / sizeof(TriangleRec), roots, p->quantise, ml, err))
+                    return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
+                if((rc = upload_array(ctx, p->d_mesh_buf, ml.slots.data(), ml.slots.size() * sizeof(TNode)))) return rc;
+                std::vector<TNode>().swap(ml.slots);
+                p->mesh_level_valid = true;
+                p->mesh_level_builds++;
+                ok = build_accel_scene_level(mesh_n, n_mesh_nodes, p->mesh_level, reinterpret_cast<const BVHNodeInfo *>(scene),
+                                             b_scene->bytes / sizeof(BVHNodeInfo), ii, n_inst, sl, err);
+            }
+            if(!ok) {
                 p->scene_level_valid = false;
                 return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
             }
-            if((rc = upload_pair(ctx, p->d_scene_buf, sl.scene_nodes.data(), sl.scene_nodes.size() * sizeof(TNode), sl.instances.data(),
-                                 sl.instances.size() * sizeof(InstAccel))))
-                return rc;
+            {
+                std::vector<char> host(sl.scene_nodes.size() * sizeof(TNode) + sl.instances.size() * sizeof(InstAccel) +
+                                       sl.wide_nodes.size() * sizeof(TNode));
+                char *w = host.data();
+                memcpy(w, sl.scene_nodes.data(), sl.scene_nodes.size() * sizeof(TNode));
+                w += sl.scene_nodes.size() * sizeof(TNode);
+                memcpy(w, sl.instances.data(), sl.instances.size() * sizeof(InstAccel));
+                w += sl.instances.size() * sizeof(InstAccel);
+                if(!sl.wide_nodes.empty()) memcpy(w, sl.wide_nodes.data(), sl.wide_nodes.size() * sizeof(TNode));
+                if((rc = upload_array(ctx, p->d_scene_buf, host.data(), host.size()))) return rc;
+            }
             p->scene_level.header = sl.header;
             p->scene_level.max_stack = sl.max_stack;
             int need = sl.max_stack + 2 - (LDS_STACK < FAST_LDS_STACK ? LDS_STACK : FAST_LDS_STACK);
@@ -972,6 +987,16 @@ int pt_pass_set_traversal(pt_pass *pass, int mode) {
     if(!pass) return fail(PT_ERR_INVALID, "pt_pass_set_traversal: null pass");
     if(mode != 0 && mode != 1) return fail(PT_ERR_INVALID, "pt_pass_set_traversal: mode must be 0 (ordered) or 1 (reference order)");
     pass->traversal_mode = mode;
+    return PT_OK;
+}
+
+int pt_pass_set_wide_nodes(pt_pass *pass, int format) {
+    if(!pass) return fail(PT_ERR_INVALID, "pt_pass_set_wide_nodes: null pass");
+    if(format < -1 || format > 1) return fail(PT_ERR_INVALID, "pt_pass_set_wide_nodes: format must be -1 (by scene size), 0 (full precision) or 1 (quantised)");
+    if(pass->quantise != format) {
+        pass->quantise = format;
+        pass->mesh_level_valid = false;  // rebuilt by the next draw / intersect
+    }
     return PT_OK;
 }
 

@@ -13,8 +13,11 @@ namespace rta {
 //
 // All traversal records are 64 bytes (an instance takes two) and live in two device buffers:
 //   mesh buffer   one slot per node of the reference's mesh BVHs, TNode (inner) or TLeaf (leaf),
-//                 each tree in depth-first order                            follows slots 2 and 4
-//   scene buffer  [ TNode x scene inner nodes | InstAccel x instances ]       follows slots 3 and 5
+//                 each tree in depth-first order; then the wide nodes        follows slots 2 and 4
+//   scene buffer  [ TNode x scene inner nodes | InstAccel x instances | wide nodes ]  follows slots 3 and 5
+// The TNodes serve the reference-order traversal, the wide nodes (the same trees, four-wide:
+// QNodes, or WNodes on request) the ordered one; both share the leaves and the
+// instance records.
 // so a step fetches base + 64 * slot whatever it is about to visit.
 // Child reference: bits 31..30 = kind, bits 29..0 = 64-byte slot in the kind's buffer.
 enum : uint32_t {
@@ -34,6 +37,38 @@ struct alignas(64) TNode {
 };
 static_assert(sizeof(TNode) == 64, "traversal node is 64 bytes");
 
+// Four-wide node of the ordered traversal, 128 bytes, 128-byte aligned (an even slot): up to
+// four subtrees of the reference's binary tree, gathered by collapsing the node with the
+// children of its larger children.  The first half reads like a TNode with two more
+// references.  A child that is a triangle carries the box of its PARENT in the reference tree
+// (the reference tests no box of the leaf itself); an absent child is REF_NONE.
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
+struct alignas(128) WNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    uint32_t c[4];
+    float lo2[3], hi2[3];
+    float lo3[3], hi3[3];
+    uint32_t pad[4];
+};
+static_assert(sizeof(WNode) == 128, "wide traversal node is 128 bytes");
+
+// The same four children in 64 bytes (the default: half the loads per visit outweighs the
+// decoding): child boxes on a grid of 256 steps per axis laid over the
+// node's box, rounded outwards, so that decoding (fma(step, scale, origin), one rounding) never
+// yields a box smaller than the exact one.  scale = 2^(e - 127) from the exponent byte e; e = 255
+// gives an infinite scale, every plane decodes to NaN and the slab test lets every ray through
+// (used when a coordinate is not finite or the extent exceeds the grid).
+struct alignas(64) QNode {
+    float origin[3];
+    uint8_t exponent[3], pad0;
+    uint32_t c[4];
+    uint8_t qlo[3][4];  // [axis][child]
+    uint8_t qhi[3][4];
+    uint32_t pad1[2];
+};
+static_assert(sizeof(QNode) == 64, "quantised wide node is 64 bytes");
+
 // Triangle leaf, 64 bytes: the exact fp32 box of the leaf's PARENT node in the reference tree
 // (the last box the reference tests before it tests the triangle; +-inf when the triangle is
 // the whole mesh; read by the ordered traversal only) followed by vertex 0 and the two edges
@@ -52,9 +87,10 @@ static_assert(sizeof(TLeaf) == 64, "triangle leaf record is 64 bytes");
 // all a ray needs to enter the instance.
 struct alignas(64) InstAccel {
     float row[3][4];
-    uint32_t root_ref;               // mesh root: inner node or, for a 1-triangle mesh, the triangle
+    uint32_t root_ref;               // mesh root: inner node (a TNode) or, for a 1-triangle mesh, the triangle
     int32_t material_ptr;
-    uint32_t pad0[2];
+    uint32_t wide_root_ref;          // the same root for the ordered traversal (a WNode or the triangle)
+    uint32_t pad0;
     float root_lo[3], root_hi[3];    // box of the mesh root (tested in local space)
     float world_lo[3], world_hi[3];  // box of the instance's scene-level leaf (tested in world space)
     uint32_t pad1[4];
@@ -64,6 +100,8 @@ static_assert(sizeof(InstAccel) == 128, "instance record is 128 bytes");
 struct SceneHeader {
     float root_lo[3], root_hi[3];  // box of scene node 0
     uint32_t root_ref;             // scene inner node 0, or the only instance
+    uint32_t wide_root_ref;        // the same for the ordered traversal (a WNode / QNode of the scene buffer)
+    uint32_t quantised;            // 1: the wide nodes of both buffers are QNodes
     uint32_t n_instances;
     float extent;                  // |x| + |y| + |z| extent of the scene box (scales absolute tolerances)
     uint32_t inst_base;            // first InstAccel slot of the scene buffer

@@ -85,7 +85,8 @@ __device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float
 
 // Source: bool load(unsigned idx, float o[3], float d[3], bool &any_hit)
 // Sink:   void store(unsigned idx, const LaneHit &h, bool ambiguous)
-template <class Source, class Sink>
+// QUANT: the wide nodes are QNodes (64 bytes, decoded on the fly) instead of WNodes.
+template <bool QUANT, class Source, class Sink>
 __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, Sink &sink, unsigned *next_ray,
                                               unsigned n_rays, uint2 *s_stack) {
 #ifndef RT_FAST_REFILL
@@ -155,7 +156,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                         tn = t0;
                     }
                     if(ray_has_nan(o, d)) have = false;  // a certain miss, see trace_core.h
-                    ref = sc.hdr.root_ref;
+                    ref = sc.hdr.wide_root_ref;
                 }
             }
             exhausted = feed.dry;
@@ -217,13 +218,14 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 else st_inner++;
             }
 #endif
-            // ---- one 64-byte fetch per served lane, whatever the entry is
-            float4 q0, q1, q2, q3;
+            // ---- one fetch per served lane: 64 bytes of a leaf, 128 of a wide node or an instance
+            float4 q0, q1, q2, q3, q4, q5, q6;
             if(go) {
                 const char *base = ((kind & 2u) ? sc.scene_buf : sc.mesh_buf) + ((size_t)idx << 6);
                 const float4 *rp = reinterpret_cast<const float4 *>(base);
                 q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3];
-            }  // (lanes that are not served leave q0..q3 unset and never read them)
+                if(QUANT ? is_inst : !is_leaf) { q4 = rp[4]; q5 = rp[5]; q6 = rp[6]; }
+            }  // (lanes that are not served leave them unset and never read them)
             // scene-level entries are met with the world ray
             if(go && kind >= REF_SCENE_INNER && in_mesh) {
                 cox = wox; coy = woy; coz = woz;
@@ -232,73 +234,95 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 in_mesh = false;
             }
 
-            // one inner node: both child boxes, nearer child next, farther one deferred
-            auto inner_step = [&](const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3, bool scene_level) {
-                float t0, t1, x0, x1;
-                slab_range(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, x0);
-                slab_range(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cix, ciy, ciz, t1, x1);
-                bool p0 = relaxed_pass(t0, x0), p1 = relaxed_pass(t1, x1);
-                const unsigned c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-                const unsigned k0 = c0 >> 30, k1 = c1 >> 30;
-                // a triangle child has no box of its own: it inherits this node's fate, which
-                // the exact parent-box test at the leaf settles; order it by this node's entry
-                if(k0 == REF_TRIANGLE) { p0 = true; t0 = tn; }
-                if(k1 == REF_TRIANGLE) { p1 = true; t1 = tn; }
-                // an instance child (scene level only): its box is the scene leaf box, whose
-                // EXACT test decides whether anything inside the instance is a candidate
-                if(scene_level) {
-                    if(k0 == REF_INSTANCE && p0 && !clear_pass(t0, x0)) {
-                        float te;
-                        p0 = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cdx, cdy, cdz, te);
-                    }
-                    if(k1 == REF_INSTANCE && p1 && !clear_pass(t1, x1)) {
-                        float te;
-                        p1 = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cdx, cdy, cdz, te);
-                    }
-                }
-                p0 = p0 && t0 <= prune_t;
-                p1 = p1 && t1 <= prune_t;
-                if(p0 && p1) {
-                    // nearer child next, farther one deferred
-                    const bool swap = t1 < t0;
-                    const unsigned rn = swap ? c1 : c0, rf = swap ? c0 : c1;
-                    const float tnn = swap ? t1 : t0, tf = swap ? t0 : t1;
-                    const uint2 e = make_uint2(rf, __float_as_uint(tf));
-                    if(sp < FAST_LDS_STACK) {
-                        s_stack[sp * FAST_BLOCK + tid] = e;
-                        ++sp;
-                    } else if(sp - FAST_LDS_STACK < sc.spill_depth) {
-                        sc.spill[(size_t)(sp - FAST_LDS_STACK) * nthreads + gtid] = e;
-                        ++sp;
-                    } else {
-                        *sc.error_flag = 1u;
-                    }
-                    ref = rn;
-                    tn = tnn;
-                } else if(p0) {
-                    ref = c0;
-                    tn = t0;
-                } else if(p1) {
-                    ref = c1;
-                    tn = t1;
+            auto push = [&](unsigned r, unsigned key) {
+                const uint2 e = make_uint2(r, key);
+                if(sp < FAST_LDS_STACK) {
+                    s_stack[sp * FAST_BLOCK + tid] = e;
+                    ++sp;
+                } else if(sp - FAST_LDS_STACK < sc.spill_depth) {
+                    sc.spill[(size_t)(sp - FAST_LDS_STACK) * nthreads + gtid] = e;
+                    ++sp;
                 } else {
-                    have = false;
+                    *sc.error_flag = 1u;
                 }
             };
             if(is_inner) {
-                inner_step(q0, q1, q2, q3, kind == REF_SCENE_INNER);
+                // one wide node: up to four child boxes; the nearest child next, the others
+                // deferred so that they come back nearest first.  Entry distances are >= 0, so
+                // their bit patterns order like the numbers and 0xFFFFFFFF marks "not taken".
+                float t0, t1, t2, t3, x0, x1, x2, x3;
+                unsigned r0, r1, r2, r3;
+                if(QUANT) {
+                    // q0 = origin, exponent bytes; q1 = references; q2 = lo.x, lo.y, lo.z, hi.x of the
+                    // four children (one byte each); q3.xy = hi.y, hi.z
+                    const unsigned eb = __float_as_uint(q0.w);
+                    const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23);
+                    const float sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
+                    const unsigned lx = __float_as_uint(q2.x), ly = __float_as_uint(q2.y), lz = __float_as_uint(q2.z);
+                    const unsigned hx = __float_as_uint(q2.w), hy = __float_as_uint(q3.x), hz = __float_as_uint(q3.y);
+#define RT_Q(packed, i, scale, org) __builtin_fmaf((float)(((packed) >> (8 * (i))) & 0xFFu), scale, org)
+#define RT_QBOX(i, T_IN, T_OUT) \
+    slab_range(RT_Q(lx, i, sx, q0.x), RT_Q(ly, i, sy, q0.y), RT_Q(lz, i, sz, q0.z), RT_Q(hx, i, sx, q0.x), RT_Q(hy, i, sy, q0.y), \
+               RT_Q(hz, i, sz, q0.z), cox, coy, coz, cix, ciy, ciz, T_IN, T_OUT)
+                    RT_QBOX(0, t0, x0);
+                    RT_QBOX(1, t1, x1);
+                    RT_QBOX(2, t2, x2);
+                    RT_QBOX(3, t3, x3);
+#undef RT_QBOX
+#undef RT_Q
+                    r0 = __float_as_uint(q1.x); r1 = __float_as_uint(q1.y); r2 = __float_as_uint(q1.z); r3 = __float_as_uint(q1.w);
+                } else {
+                    slab_range(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, x0);
+                    slab_range(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cix, ciy, ciz, t1, x1);
+                    slab_range(q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, cox, coy, coz, cix, ciy, ciz, t2, x2);
+                    slab_range(q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, cox, coy, coz, cix, ciy, ciz, t3, x3);
+                    r0 = __float_as_uint(q3.x); r1 = __float_as_uint(q3.y); r2 = __float_as_uint(q3.z); r3 = __float_as_uint(q3.w);
+                }
+                unsigned k0 = relaxed_pass(t0, x0) && t0 <= prune_t ? __float_as_uint(t0) : 0xFFFFFFFFu;
+                unsigned k1 = relaxed_pass(t1, x1) && t1 <= prune_t ? __float_as_uint(t1) : 0xFFFFFFFFu;
+                unsigned k2 = r2 != REF_NONE && relaxed_pass(t2, x2) && t2 <= prune_t ? __float_as_uint(t2) : 0xFFFFFFFFu;
+                unsigned k3 = r3 != REF_NONE && relaxed_pass(t3, x3) && t3 <= prune_t ? __float_as_uint(t3) : 0xFFFFFFFFu;
+                auto order = [](unsigned &ka, unsigned &ra, unsigned &kb, unsigned &rb) {
+                    const bool sw = kb < ka;
+                    const unsigned kl = sw ? kb : ka, kh = sw ? ka : kb, rl = sw ? rb : ra, rh = sw ? ra : rb;
+                    ka = kl; kb = kh; ra = rl; rb = rh;
+                };
+                order(k0, r0, k1, r1);
+                order(k2, r2, k3, r3);
+                order(k0, r0, k2, r2);
+                order(k1, r1, k3, r3);
+                order(k1, r1, k2, r2);
+                if(k0 == 0xFFFFFFFFu) {
+                    have = false;
+                } else {
+                    if(k3 != 0xFFFFFFFFu) push(r3, k3);
+                    if(k2 != 0xFFFFFFFFu) push(r2, k2);
+                    if(k1 != 0xFFFFFFFFu) push(r1, k1);
+                    ref = r0;
+                    tn = __uint_as_float(k0);
+                }
             } else if(serve_inst && is_inst) {
-                // entry into the instance: rows of world-to-local, then the mesh root
-                cox = (q0.x * wox + q0.y * woy) + (q0.z * woz + q0.w);
-                coy = (q1.x * wox + q1.y * woy) + (q1.z * woz + q1.w);
-                coz = (q2.x * wox + q2.y * woy) + (q2.z * woz + q2.w);
-                cdx = (q0.x * wdx + q0.y * wdy) + q0.z * wdz;
-                cdy = (q1.x * wdx + q1.y * wdy) + q1.z * wdz;
-                cdz = (q2.x * wdx + q2.y * wdy) + q2.z * wdz;
-                cix = fast_rcp(cdx); ciy = fast_rcp(cdy); ciz = fast_rcp(cdz);
-                in_mesh = true;
-                cur_inst = (int)((idx - sc.hdr.inst_base) >> 1);
-                ref = __float_as_uint(q3.x);  // mesh root; its own box is implied by the boxes below it
+                // the instance's box is its scene leaf box, whose EXACT test decides whether
+                // anything inside the instance is a candidate (world_lo / world_hi of InstAccel)
+                bool clear;
+                float tw;
+                bool pass = slab_fast(q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, cox, coy, coz, cix, ciy, ciz, tw, clear);
+                if(pass && !clear) pass = slab_test(q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, cox, coy, coz, cdx, cdy, cdz, tw);
+                if(!pass) {
+                    have = false;
+                } else {
+                    // entry into the instance: rows of world-to-local, then the mesh root
+                    cox = (q0.x * wox + q0.y * woy) + (q0.z * woz + q0.w);
+                    coy = (q1.x * wox + q1.y * woy) + (q1.z * woz + q1.w);
+                    coz = (q2.x * wox + q2.y * woy) + (q2.z * woz + q2.w);
+                    cdx = (q0.x * wdx + q0.y * wdy) + q0.z * wdz;
+                    cdy = (q1.x * wdx + q1.y * wdy) + q1.z * wdz;
+                    cdz = (q2.x * wdx + q2.y * wdy) + q2.z * wdz;
+                    cix = fast_rcp(cdx); ciy = fast_rcp(cdy); ciz = fast_rcp(cdz);
+                    in_mesh = true;
+                    cur_inst = (int)((idx - sc.hdr.inst_base) >> 1);
+                    ref = __float_as_uint(q3.z);  // wide mesh root; its own box is implied by the boxes below it
+                }
             } else if(serve_leaf && is_leaf) {
                 // triangle leaf: q0, q1.xy parent box; then v0, e1, e2
                 const float v0x = q1.z, v0y = q1.w, v0z = q2.x;

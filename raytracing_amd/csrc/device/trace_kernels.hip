@@ -65,13 +65,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void intersect_kernel(TraceScene sc, c
     trace_persistent(sc, src, sink, next_counter, redo ? *redo_count : n, s_stack);
 }
 
+template <bool QUANT>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void intersect_fast_kernel(FastScene sc, const float *rays, unsigned n,
                                                                     pt_hit *hits, unsigned *next_counter,
                                                                     unsigned *redo, unsigned *redo_count) {
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
     RaySource src{rays, nullptr};
     HitSinkFast sink{hits, redo, redo_count};
-    trace_ordered(sc, src, sink, next_counter, n, s_stack);
+    trace_ordered<QUANT>(sc, src, sink, next_counter, n, s_stack);
 }
 
 // ---- extend ------------------------------------------------------------------------------
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void extend_kernel(TraceScene sc, cons
     trace_persistent(sc, src, sink, next_counter, *count, s_stack);
 }
 
+template <bool QUANT>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_fast_kernel(FastScene sc, const unsigned *queue,
                                                                  const unsigned *count, const PathRay *rays,
                                                                  PathHit *hits, unsigned *next_counter,
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_fast_kernel(Fas
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
     ExtendSource src{queue, rays};
     ExtendSinkFast sink{queue, hits, redo, redo_count};
-    trace_ordered(sc, src, sink, next_counter, *count, s_stack);
+    trace_ordered<QUANT>(sc, src, sink, next_counter, *count, s_stack);
 }
 
 // ---- shadow ------------------------------------------------------------------------------
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void shadow_kernel(TraceScene sc, cons
 }
 
 // sky-only form (n_shadow == 1): every query is an occlusion query
+template <bool QUANT>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_fast_kernel(FastScene sc, const unsigned *queue,
                                                                  const unsigned *count, const PathRay *rays,
                                                                  ShadowEntry *shadow, int npix,
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_fast_kernel(Fas
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
     ShadowSource src{queue, rays, shadow, 1, npix};
     ShadowSink sink{queue, shadow, 1, npix};
-    trace_ordered(sc, src, sink, next_counter, *count, s_stack);
+    trace_ordered<QUANT>(sc, src, sink, next_counter, *count, s_stack);
 }
 
 // ---- shadow rays of vertex d and extend rays of vertex d+1 in ONE launch ---------------------
@@ -211,6 +214,7 @@ struct PathSink {
     }
 };
 
+template <bool QUANT>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel(
     FastScene sc, const unsigned *queue_e, const unsigned *count_e, const unsigned *queue_s, const unsigned *count_s,
     const PathRay *rays, PathHit *hits, ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo,
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel
     const unsigned n_e = *count_e, n_s = *count_s;
     PathSource src{ExtendSource{queue_e, rays}, ShadowSource{queue_s, rays, shadow, 1, npix}, n_e};
     PathSink sink{ExtendSinkFast{queue_e, hits, redo, redo_count}, ShadowSink{queue_s, shadow, 1, npix}, n_e};
-    trace_ordered(sc, src, sink, next_counter, n_e + n_s, s_stack);
+    trace_ordered<QUANT>(sc, src, sink, next_counter, n_e + n_s, s_stack);
 }
 
 }  // namespace
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel
 void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue_e, const unsigned *count_e,
                             const unsigned *queue_s, const unsigned *count_s, const PathRay *rays, PathHit *hits,
                             ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo, unsigned *redo_count) {
-    hipLaunchKernelGGL(path_trace_fast_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue_e, count_e, queue_s, count_s, rays,
+    hipLaunchKernelGGL(sc.hdr.quantised ? path_trace_fast_kernel<true> : path_trace_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue_e, count_e, queue_s, count_s, rays,
                        hits, shadow, npix, next_counter, redo, redo_count);
 }
 
@@ -239,7 +243,7 @@ void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const flo
 
 void launch_intersect_fast(hipStream_t s, const FastScene &sc, int blocks, const float *rays, unsigned n,
                            pt_hit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count) {
-    hipLaunchKernelGGL(intersect_fast_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, rays, n, hits, next_counter,
+    hipLaunchKernelGGL(sc.hdr.quantised ? intersect_fast_kernel<true> : intersect_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, rays, n, hits, next_counter,
                        redo, redo_count);
 }
 
@@ -252,7 +256,7 @@ void launch_extend(hipStream_t s, const TraceScene &sc, int blocks, const unsign
 void launch_extend_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                         const PathRay *rays, PathHit *hits, unsigned *next_counter, unsigned *redo,
                         unsigned *redo_count) {
-    hipLaunchKernelGGL(extend_fast_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, hits,
+    hipLaunchKernelGGL(sc.hdr.quantised ? extend_fast_kernel<true> : extend_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, hits,
                        next_counter, redo, redo_count);
 }
 
@@ -264,7 +268,7 @@ void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsign
 
 void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                         const PathRay *rays, ShadowEntry *shadow, int npix, unsigned *next_counter) {
-    hipLaunchKernelGGL(shadow_fast_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, shadow, npix,
+    hipLaunchKernelGGL(sc.hdr.quantised ? shadow_fast_kernel<true> : shadow_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, shadow, npix,
                        next_counter);
 }
 

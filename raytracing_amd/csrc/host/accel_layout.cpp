@@ -26,10 +26,162 @@ bool check_children(const BVHNodeInfo *nodes, size_t n, size_t i, const char *wh
     return true;
 }
 
+float half_area(const BVHNodeInfo &n) {
+    const float x = n.bb[0] - n.aa[0], y = n.bb[1] - n.aa[1], z = n.bb[2] - n.aa[2];
+    return x * y + y * z + z * x;
+}
+
+// Collapses binary trees (child index > parent index) into four-wide nodes.  A node takes its
+// two children and then, while it has room, replaces the inner child of largest surface by
+// that child's two children.  is_leaf(i) tells leaves; leaf_ref(i) / the returned slot numbers
+// make the references; a leaf child carries its reference parent's box when
+// leaf_box_of_parent, else its own.  Wide node k gets slot slot_base + 2 k.
+// Child boxes of one wide node on the node's 256-step grid, rounded outwards as decoded:
+// fmaf(step, 2^(e - 127), origin) <= lo and >= hi in fp32.
+void quantise_node(const uint32_t refs[4], const BVHNodeInfo *const boxes[4], QNode &q) {
+    memset(&q, 0, sizeof q);
+    for(int i = 0; i < 4; i++) q.c[i] = refs[i];
+    for(int a = 0; a < 3; a++) {
+        bool finite = true;
+        float o = std::numeric_limits<float>::infinity(), top = -std::numeric_limits<float>::infinity();
+        for(int i = 0; i < 4; i++)
+            if(boxes[i]) {
+                const float l = boxes[i]->aa[a], h = boxes[i]->bb[a];
+                if(!std::isfinite(l) || !std::isfinite(h)) finite = false;
+                o = std::min(o, std::min(l, h));
+                top = std::max(top, std::max(l, h));
+            }
+        int e = 255;
+        if(finite) {
+            // smallest scale whose 255th step reaches the top
+            int guess = 1;
+            const double ext = (double)top - (double)o;
+            if(ext > 0.0) {
+                int ex;
+                std::frexp(ext / 255.0, &ex);  // ext / 255 = m * 2^ex, m in [0.5, 1)
+                guess = std::max(1, std::min(254, ex + 127 - 1));
+            }
+            for(e = guess; e < 255; e++) {
+                const float s = std::ldexp(1.0f, e - 127);
+                const float reach = std::fmaf(255.0f, s, o);
+                if(std::isfinite(reach) && reach >= top) break;
+            }
+        }
+        q.origin[a] = finite ? o : 0.0f;
+        q.exponent[a] = (uint8_t)e;
+        if(e == 255) continue;  // every plane decodes to NaN: the axis constrains nothing
+        const float s = std::ldexp(1.0f, e - 127);
+        for(int i = 0; i < 4; i++) {
+            if(!boxes[i]) continue;
+            const float l = boxes[i]->aa[a], h = boxes[i]->bb[a];
+            int ql = (int)std::floor(((double)l - (double)o) / (double)s);
+            ql = std::max(0, std::min(255, ql));
+            while(ql > 0 && std::fmaf((float)ql, s, o) > l) ql--;
+            int qh = (int)std::ceil(((double)h - (double)o) / (double)s);
+            qh = std::max(0, std::min(255, qh));
+            while(qh < 255 && std::fmaf((float)qh, s, o) < h) qh++;
+            q.qlo[a][i] = (uint8_t)ql;
+            q.qhi[a][i] = (uint8_t)qh;
+        }
+    }
+}
+
+template <class IsLeaf, class LeafRef>
+void build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::vector<int32_t> &roots, IsLeaf is_leaf,
+                      LeafRef leaf_ref, bool leaf_box_of_parent, uint32_t inner_kind, uint32_t slot_base, bool quantised,
+                      std::vector<TNode> &out, std::vector<uint32_t> &wide_of, std::vector<uint8_t> &wide_height) {
+    const uint32_t stride = quantised ? 1u : 2u;  // slots per wide node
+    wide_of.assign(n_nodes, REF_NONE);
+    out.clear();
+    struct Kids { int32_t k[4]; };
+    std::vector<Kids> kids;  // inner children (reference node indices) of each wide node, -1 = none
+    std::vector<int32_t> work, owner;  // owner[k] = reference node of wide node k
+    auto wide_slot = [&](int32_t node) {
+        if(wide_of[node] == REF_NONE) {
+            wide_of[node] = slot_base + (uint32_t)out.size();
+            out.resize(out.size() + stride);
+            kids.push_back(Kids{{-1, -1, -1, -1}});
+            owner.push_back(node);
+            work.push_back(node);
+        }
+        return wide_of[node];
+    };
+    for(int32_t r : roots)
+        if(r >= 0 && (size_t)r < n_nodes && !is_leaf(r)) wide_slot(r);
+    while(!work.empty()) {
+        const int32_t n = work.back();
+        work.pop_back();
+        struct Item { int32_t node, parent; } items[4];
+        int cnt = 2;
+        items[0] = {nodes[n].lsIndex, n};
+        items[1] = {nodes[n].rsIndex, n};
+        while(cnt < 4) {
+            int best = -1;
+            float best_area = -1.0f;
+            for(int i = 0; i < cnt; i++)
+                if(!is_leaf(items[i].node)) {
+                    const float a = half_area(nodes[items[i].node]);
+                    if(a > best_area || best < 0) {
+                        best_area = a;
+                        best = i;
+                    }
+                }
+            if(best < 0) break;
+            const int32_t c = items[best].node;
+            for(int i = cnt; i > best + 1; i--) items[i] = items[i - 1];
+            items[best] = {nodes[c].lsIndex, c};
+            items[best + 1] = {nodes[c].rsIndex, c};
+            cnt++;
+        }
+        const size_t k = (wide_of[n] - slot_base) / stride;
+        uint32_t refs[4];
+        const BVHNodeInfo *boxes[4];
+        for(int i = 0; i < 4; i++) {
+            refs[i] = REF_NONE;
+            boxes[i] = nullptr;
+            if(i >= cnt) continue;
+            const int32_t c = items[i].node;
+            if(is_leaf(c)) {
+                refs[i] = leaf_ref(c);
+                boxes[i] = &nodes[leaf_box_of_parent ? items[i].parent : c];
+            } else {
+                refs[i] = make_ref(inner_kind, wide_slot(c));  // (may grow `out`: it is indexed again below)
+                boxes[i] = &nodes[c];
+                kids[k].k[i] = c;
+            }
+        }
+        if(quantised) {
+            quantise_node(refs, boxes, *reinterpret_cast<QNode *>(&out[k]));
+        } else {
+            WNode &w = *reinterpret_cast<WNode *>(&out[2 * k]);
+            memset(&w, 0, sizeof w);
+            float *lo[4] = {w.lo0, w.lo1, w.lo2, w.lo3}, *hi[4] = {w.hi0, w.hi1, w.hi2, w.hi3};
+            for(int i = 0; i < 4; i++) {
+                w.c[i] = refs[i];
+                for(int a = 0; a < 3; a++) {
+                    lo[i][a] = boxes[i] ? boxes[i]->aa[a] : 0.0f;
+                    hi[i][a] = boxes[i] ? boxes[i]->bb[a] : 0.0f;
+                }
+            }
+        }
+    }
+    // heights, children before parents (a child's reference index is larger than its parent's)
+    wide_height.assign(owner.size(), 1);
+    std::vector<uint32_t> order(owner.size());
+    for(size_t k = 0; k < owner.size(); k++) order[k] = (uint32_t)k;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return owner[a] > owner[b]; });
+    for(uint32_t k : order) {
+        int h = 1;
+        for(int i = 0; i < 4; i++)
+            if(kids[k].k[i] >= 0) h = std::max<int>(h, 1 + wide_height[(wide_of[kids[k].k[i]] - slot_base) / stride]);
+        wide_height[k] = (uint8_t)std::min(h, 255);
+    }
+}
+
 }  // namespace
 
 bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const TriangleRec *tris, size_t n_tris,
-                            AccelMeshLevel &out, std::string &err) {
+                            const std::vector<int32_t> &extra_roots, int quantise, AccelMeshLevel &out, std::string &err) {
     if(n_mesh_nodes == 0 || n_tris == 0) {
         err = "scene buffers must not be empty (mesh BVH, triangles)";
         return false;
@@ -110,12 +262,33 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
         const int h = std::max<int>(out.height[p.lsIndex], out.height[p.rsIndex]) + 1;
         out.height[ii] = (uint8_t)std::min(h, 255);
     }
+    // ---- the same trees, four-wide, for the ordered traversal
+    std::vector<int32_t> roots;
+    for(size_t r = 0; r < n_mesh_nodes; r++)
+        if(!has_parent[r]) roots.push_back((int32_t)r);
+    roots.insert(roots.end(), extra_roots.begin(), extra_roots.end());
+    out.quantised = quantise != 0;
+    out.wide_stride = out.quantised ? 1u : 2u;
+    out.wide_base = (next + 1u) & ~1u;
+    std::vector<TNode> wide;
+    build_wide_nodes(
+        mesh, n_mesh_nodes, roots, [&](int32_t c) { return mesh[c].triangleIndex >= 0; },
+        [&](int32_t c) { return make_ref(REF_TRIANGLE, slot_of[c]); }, true, REF_MESH_INNER, out.wide_base, out.quantised, wide,
+        out.wide_of, out.wide_height);
+    if((uint64_t)out.wide_base + (uint64_t)wide.size() >= REF_INDEX_MASK) {
+        err = "scene too large for 30-bit references";
+        return false;
+    }
+    out.slots.resize((size_t)out.wide_base + wide.size());
+    if(out.wide_base > next) memset(&out.slots[next], 0, sizeof(TNode));
+    if(!wide.empty()) memcpy(&out.slots[out.wide_base], wide.data(), wide.size() * sizeof(TNode));
     return true;
 }
 
 bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const AccelMeshLevel &ml, const BVHNodeInfo *scene,
                              size_t n_scene_nodes, const InstanceInfo *inst, size_t n_inst, AccelSceneLevel &out,
-                             std::string &err) {
+                             std::string &err, bool *missing_root) {
+    if(missing_root) *missing_root = false;
     if(n_scene_nodes == 0 || n_inst == 0) {
         err = "scene buffers must not be empty (scene BVH, instances)";
         return false;
@@ -131,7 +304,7 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
     auto mesh_ref = [&](int32_t c) { return make_ref(mesh[c].triangleIndex >= 0 ? REF_TRIANGLE : REF_MESH_INNER, ml.slot_of[c]); };
     // ---- instances
     out.instances.resize(n_inst);
-    int max_mesh_height = 1;
+    int max_mesh_height = 1, max_wide_height = 0;
     for(size_t i = 0; i < n_inst; i++) {
         const InstanceInfo &s = inst[i];
         if(s.meshIndex < 0 || (size_t)s.meshIndex >= n_mesh_nodes) {
@@ -148,12 +321,23 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
         const BVHNodeInfo &root = mesh[s.meshIndex];
         set_box(a.root_lo, a.root_hi, root);
         a.root_ref = mesh_ref(s.meshIndex);
+        if(root.triangleIndex >= 0) {
+            a.wide_root_ref = a.root_ref;
+        } else {
+            if(ml.wide_of[s.meshIndex] == REF_NONE) {
+                if(missing_root) *missing_root = true;
+                err = "instance " + std::to_string(i) + " starts at a node that is not a mesh root";
+                return false;
+            }
+            a.wide_root_ref = make_ref(REF_MESH_INNER, ml.wide_of[s.meshIndex]);
+            max_wide_height = std::max<int>(max_wide_height, ml.wide_height[(ml.wide_of[s.meshIndex] - ml.wide_base) / ml.wide_stride]);
+        }
         a.material_ptr = s.materialPtr;
         for(int k = 0; k < 3; k++) {
             a.world_lo[k] = 0.0f;
             a.world_hi[k] = 0.0f;
         }
-        memset(a.pad0, 0, sizeof a.pad0);
+        a.pad0 = 0;
         memset(a.pad1, 0, sizeof a.pad1);
         max_mesh_height = std::max<int>(max_mesh_height, ml.height[s.meshIndex]);
     }
@@ -171,8 +355,8 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
             sinner_of[i] = n_sinner++;
         }
     }
-    const uint32_t inst_base = std::max<uint32_t>(n_sinner, 1u);
-    if((uint64_t)inst_base + 2 * (uint64_t)n_inst >= REF_INDEX_MASK) {
+    const uint32_t inst_base = (std::max<uint32_t>(n_sinner, 1u) + 1u) & ~1u;  // even: the records behind are 128-byte aligned
+    if((uint64_t)inst_base + 2 * (uint64_t)n_inst + 2 * (uint64_t)n_sinner >= REF_INDEX_MASK) {
         err = "scene too large for 30-bit references";
         return false;
     }
@@ -204,8 +388,18 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
     out.header.root_ref = scene_ref(0);
     out.header.n_instances = (uint32_t)n_inst;
     out.header.inst_base = inst_base;
-    // each level of a walk defers at most one sibling
-    out.max_stack = sheight[0] + max_mesh_height;
+    // ---- the scene tree four-wide (an instance child keeps its own box: the scene leaf box)
+    std::vector<uint32_t> swide_of;
+    std::vector<uint8_t> swide_height;
+    build_wide_nodes(
+        scene, n_scene_nodes, std::vector<int32_t>{0}, [&](int32_t c) { return scene[c].instanceIndex >= 0; },
+        [&](int32_t c) { return scene_ref(c); }, false, REF_SCENE_INNER, inst_base + 2u * (uint32_t)n_inst, ml.quantised,
+        out.wide_nodes, swide_of, swide_height);
+    out.header.quantised = ml.quantised ? 1u : 0u;
+    out.header.wide_root_ref = scene[0].instanceIndex >= 0 ? out.header.root_ref : make_ref(REF_SCENE_INNER, swide_of[0]);
+    // reference order: each level of a walk defers at most one sibling; ordered walk: three per wide level
+    const int wide_stack = 3 * ((swide_height.empty() ? 0 : swide_height[0]) + max_wide_height);
+    out.max_stack = std::max(sheight[0] + max_mesh_height, wide_stack);
     return true;
 }
 

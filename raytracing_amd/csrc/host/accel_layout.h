@@ -16,6 +16,11 @@ struct AccelMeshLevel {
     // kept on the host for the scene level (instances name their mesh root by node index)
     std::vector<uint32_t> slot_of;      // reference node index -> slot
     std::vector<uint8_t> height;        // height of the subtree under each reference node, capped at 255
+    std::vector<uint32_t> wide_of;      // reference node index -> slot of its WNode, REF_NONE if it has none
+    std::vector<uint8_t> wide_height;   // per wide node (by (slot - wide_base) / wide_stride): height of the wide subtree
+    uint32_t wide_base = 0;             // first wide-node slot
+    uint32_t wide_stride = 2;           // slots per wide node: 2 (WNode) or 1 (QNode)
+    bool quantised = false;
     size_t n_tris = 0;
 };
 
@@ -24,15 +29,20 @@ struct AccelMeshLevel {
 struct AccelSceneLevel {
     std::vector<TNode> scene_nodes;     // slots [0, inst_base) of the scene buffer
     std::vector<InstAccel> instances;   // two slots each from inst_base on
+    std::vector<TNode> wide_nodes;      // WNodes (two slots each) or QNodes after the instances, as raw slots
     SceneHeader header;
     int max_stack = 0;  // upper bound of deferred entries one ray can hold (scene + mesh height)
 };
 
 // Both return false and set err when the buffers are inconsistent.
+// Every node without a parent gets a wide tree; extra_roots names further nodes that instances
+// use as mesh roots.  The scene level sets missing_root (and fails) when an instance names an
+// inner node that has none: the caller rebuilds the mesh level with those roots.
+// quantise: 0 = WNodes, 1 or -1 (the default choice) = QNodes, which measured faster on small and large scenes alike.
 bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const TriangleRec *tris, size_t n_tris,
-                            AccelMeshLevel &out, std::string &err);
+                            const std::vector<int32_t> &extra_roots, int quantise, AccelMeshLevel &out, std::string &err);
 bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const AccelMeshLevel &ml, const BVHNodeInfo *scene,
                              size_t n_scene_nodes, const InstanceInfo *inst, size_t n_inst, AccelSceneLevel &out,
-                             std::string &err);
+                             std::string &err, bool *missing_root = nullptr);
 
 }  // namespace rta

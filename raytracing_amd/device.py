@@ -241,6 +241,10 @@ class PathTracingPass:
         """0 = ordered traversal with exact fallback (default), 1 = reference order only."""
         check(lib.pt_pass_set_traversal(self.h, int(mode)))
 
+    def set_wide_nodes(self, fmt):
+        """Node format of the ordered traversal: -1 the library's choice (default), 0 fp32 boxes, 1 quantised."""
+        check(lib.pt_pass_set_wide_nodes(self.h, int(fmt)))
+
     def set_pipeline(self, draws_in_flight):
         """How many draws may overlap on the device (1..8); outputs do not depend on it."""
         check(lib.pt_pass_set_pipeline(self.h, int(draws_in_flight)))

@@ -34,6 +34,31 @@ def test_casa_random_rays(casa, oracle_mod, gpu_ctx):
     sb.release()
 
 
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_both_wide_node_formats(casa, oracle_mod, gpu_ctx, fmt):
+    """pt_pass_set_wide_nodes: full-precision and quantised four-wide nodes give the same hits;
+    switching the format on a live pass rebuilds the mesh level."""
+    from raytracing_amd import device
+    lo, hi = casa.world_box()
+    rays = random_rays(lo, hi, 1 << 19, 23 + fmt)
+    sb = device.SceneBuffers(gpu_ctx, casa)
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    p.bind_scene(sb)
+    p.set_wide_nodes(fmt)
+    hits = device.trace_rays(p, rays)
+    ref, _ = oracle_mod.OracleScene(casa).intersect(rays)
+    _check(hits, ref)
+    builds = p.stats()["mesh_level_builds"]
+    p.set_wide_nodes(1 - fmt)
+    hits = device.trace_rays(p, rays)
+    _check(hits, ref)
+    assert p.stats()["mesh_level_builds"] == builds + 1
+    with pytest.raises(Exception):
+        p.set_wide_nodes(2)
+    p.destroy()
+    sb.release()
+
+
 def test_reference_order_mode_matches_too(casa, oracle_mod, gpu_ctx):
     """pt_pass_set_traversal(1): every ray in the reference's visiting order."""
     from raytracing_amd import device

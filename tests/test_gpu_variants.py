@@ -21,12 +21,13 @@ def mixed_scene():
     return scene.synthetic_scene(30_000, seed=99, dielectric_fraction=0.5, lights=3, textures=5, texture_size=64)
 
 
-def run(gpu_ctx, oracle_mod, sd, sky, w, h, spps, traversal=0, pipeline=3, **kw):
+def run(gpu_ctx, oracle_mod, sd, sky, w, h, spps, traversal=0, pipeline=3, wide_nodes=-1, **kw):
     from raytracing_amd import device, scene
     sb = device.SceneBuffers(gpu_ctx, sd, sky)
     p = device.PathTracingPass(gpu_ctx, w, h)
     p.bind_scene(sb)
     p.set_traversal(traversal)
+    p.set_wide_nodes(wide_nodes)
     p.set_pipeline(pipeline)
     osc = oracle_mod.OracleScene(sd, sky)
     v2w = scene.synthetic_camera()
@@ -50,9 +51,10 @@ def check(out, ref, st=None, cnt=None):
         assert st["rays_extend"] == cnt["rays_extend"] and st["rays_shadow"] == cnt["rays_shadow"]
 
 
-def test_dielectrics_and_lights(mixed_scene, small_sky, oracle_mod, gpu_ctx):
+@pytest.mark.parametrize("wide_nodes", [0, 1])
+def test_dielectrics_and_lights(mixed_scene, small_sky, oracle_mod, gpu_ctx, wide_nodes):
     assert len(mixed_scene.lights) == 3
-    out, ref, st, cnt = run(gpu_ctx, oracle_mod, mixed_scene, small_sky, 128, 72, [1], max_depth=4)
+    out, ref, st, cnt = run(gpu_ctx, oracle_mod, mixed_scene, small_sky, 128, 72, [1], max_depth=4, wide_nodes=wide_nodes)
     check(out, ref, st, cnt)
     assert cnt["rays_shadow"] > cnt["rays_extend"]  # three light rays + one sky ray per shaded vertex
     assert np.isfinite(out["directLum"]).all() and out["directLum"].max() > 0
