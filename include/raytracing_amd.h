@@ -170,7 +170,12 @@ typedef struct pt_stats {
      * every frame while instances move); not reset. */
     uint64_t mesh_level_builds, scene_level_builds;
     uint64_t debug[3];       /* step counters of RT_TRACE_STATS builds, else 0 */
-    uint64_t reserved[2];
+    /* 1 when the bound BVH buffers hold a child box that is not inside its parent's box (the
+     * reference's builder never makes one, src/BVH.cpp:11-82): the ordered traversal's
+     * equivalence to the reference's order rests on that nesting, so such buffers are traced
+     * in the reference's order whatever pt_pass_set_traversal says.  Not reset. */
+    uint64_t reference_order_forced;
+    uint64_t reserved[1];
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 
@@ -294,6 +299,17 @@ int pt_host_build_mesh_bvh(const void *tris, const int32_t *tri_count, int32_t n
 int pt_host_build_scene(const float *mesh_root_box, const int32_t *mesh_siz, const int32_t *mesh_depth,
                         int32_t n_mesh, const float *l2w, const int32_t *mesh_index, const int32_t *material_ptr,
                         int32_t n_inst, void *instance_info_out, void *scene_nodes_out, int32_t *stats_out);
+/* No counterpart in the reference (test and debugging aid; no GPU).  Builds, from
+ * reference-format buffers (slots 4, 2, 5, 3), the records the traversal kernels read and
+ * checks them independently: every four-wide tree reaches exactly the triangles / instances
+ * of its binary tree, every child box as the kernel decodes it contains the reference's box,
+ * references stay inside the buffers, the stack bound holds.  format as in
+ * pt_pass_set_wide_nodes.  counts_out (optional): wide mesh nodes, wide scene nodes, child
+ * boxes checked, box planes that decode to "unbounded".  PT_ERR_INVALID when the buffers are
+ * refused (as pt_pass_draw would), PT_ERR_STATE when a check fails. */
+int pt_host_check_traversal_layout(const void *mesh_nodes, size_t n_mesh_nodes, const void *tris, size_t n_tris,
+                                   const void *scene_nodes, size_t n_scene_nodes, const void *instances, size_t n_inst,
+                                   int32_t format, uint64_t counts_out[4]);
 /* Transform::matrix, src/Transform.cpp:20-53 */
 int pt_host_transform_matrix(const float position[3], const float rotation_deg[3], const float scale[3],
                              float out16[16]);

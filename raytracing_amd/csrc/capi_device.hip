@@ -305,6 +305,7 @@ int prepare_scene(pt_pass *p) {
             }
             p->scene_level.header = sl.header;
             p->scene_level.max_stack = sl.max_stack;
+            p->scene_level.nested = sl.nested;
             int need = sl.max_stack + 2 - (LDS_STACK < FAST_LDS_STACK ? LDS_STACK : FAST_LDS_STACK);
             if(need < 0) need = 0;
             if(need > p->spill_depth || !p->d_spill.p) {
@@ -351,6 +352,10 @@ int prepare_scene(pt_pass *p) {
     }
     return PT_OK;
 }
+
+// The ordered traversal is equivalent to the reference's order only when child boxes lie
+// inside their parents' boxes; other buffers are traced in the reference's order.
+bool use_ordered(const pt_pass *p) { return p->traversal_mode == 0 && p->mesh_level.nested && p->scene_level.nested; }
 
 // spill == nullptr: the pass's own spill area (launches on the main stream)
 TraceScene make_trace_scene(pt_pass *p, void *spill = nullptr) {
@@ -842,7 +847,7 @@ int pt_pass_draw(pt_pass *p) {
     dp.stats = static_cast<unsigned long long *>(p->d_stats.p);
     unsigned *cnt = static_cast<unsigned *>(L.counters.p);
     dp.counters = cnt;
-    dp.redo_counter_base = p->traversal_mode == 0 ? CNT_REDO : -1;
+    dp.redo_counter_base = use_ordered(p) ? CNT_REDO : -1;
 
     hipStream_t s = L.stream;
     p->cur_stream = s;
@@ -851,7 +856,7 @@ int pt_pass_draw(pt_pass *p) {
     HIP_TRY(hipStreamWaitEvent(s, L.start, 0));
     const TraceScene sc = make_trace_scene(p, L.spill.p);
     const FastScene fsc = make_fast_scene(p, L.spill.p);
-    const bool ordered = p->traversal_mode == 0;
+    const bool ordered = use_ordered(p);
     unsigned *qr = static_cast<unsigned *>(L.queue_r.p);
     HIP_TRY(hipMemsetAsync(cnt, 0, CNT_TOTAL * 4, s));
     {
@@ -970,6 +975,7 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     out->draws = raw[3];
     out->rays_retraced = raw[4];
     out->mesh_level_builds = pass->mesh_level_builds;
+    out->reference_order_forced = pass->mesh_level_valid && pass->scene_level_valid && !(pass->mesh_level.nested && pass->scene_level.nested) ? 1 : 0;
     out->scene_level_builds = pass->scene_level_builds;
     HIP_TRY(hipMemcpy(out->debug, static_cast<char *>(pass->d_err.p) + 16, 24, hipMemcpyDeviceToHost));
     if(reset) {
@@ -1035,12 +1041,12 @@ int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
     p->cur_stream = s;
     HIP_TRY(hipMemsetAsync(cnt + CNT_INTERSECT, 0, 12, s));
     const TraceScene sc = make_trace_scene(p);
-    if(p->traversal_mode == 0 && (rc = p->d_redo_isect.ensure(n * 4))) return rc;
+    if(use_ordered(p) && (rc = p->d_redo_isect.ensure(n * 4))) return rc;
     long long blocks = ((long long)n + TRACE_BLOCK - 1) / TRACE_BLOCK;
     if(blocks > p->trace_blocks) blocks = p->trace_blocks;
     {
         ScopedTimer t(p, K_INTERSECT);
-        if(p->traversal_mode == 0) {
+        if(use_ordered(p)) {
             unsigned *redo = static_cast<unsigned *>(p->d_redo_isect.p);
             launch_intersect_fast(s, make_fast_scene(p), (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n,
                                   static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT, redo, cnt + CNT_INTERSECT + 1);

@@ -7,6 +7,7 @@
 #include "host/scene_host.h"
 #include "host/sky_host.h"
 #include "host/png_writer.h"
+#include "host/accel_layout.h"
 
 namespace rta {
 static thread_local std::string g_last_error;
@@ -75,6 +76,35 @@ int pt_host_build_scene(const float *mesh_root_box, const int32_t *mesh_siz, con
     memcpy(instance_info_out, sl.instances.data(), sl.instances.size() * sizeof(InstanceInfo));
     memcpy(scene_nodes_out, sl.nodes.data(), sl.nodes.size() * sizeof(BVHNodeInfo));
     if(stats_out) { stats_out[0] = sl.siz; stats_out[1] = sl.depth; }
+    return PT_OK;
+}
+
+int pt_host_check_traversal_layout(const void *mesh_nodes, size_t n_mesh_nodes, const void *tris, size_t n_tris,
+                                   const void *scene_nodes, size_t n_scene_nodes, const void *instances, size_t n_inst,
+                                   int32_t format, uint64_t counts_out[4]) {
+    if(!mesh_nodes || !tris || !scene_nodes || !instances) return fail(PT_ERR_INVALID, "pt_host_check_traversal_layout: null argument");
+    if(format < -1 || format > 1) return fail(PT_ERR_INVALID, "pt_host_check_traversal_layout: format must be -1, 0 or 1");
+    const BVHNodeInfo *mesh = static_cast<const BVHNodeInfo *>(mesh_nodes), *scene = static_cast<const BVHNodeInfo *>(scene_nodes);
+    const InstanceInfo *inst = static_cast<const InstanceInfo *>(instances);
+    std::string err;
+    AccelMeshLevel ml;
+    AccelSceneLevel sl;
+    if(!build_accel_mesh_level(mesh, n_mesh_nodes, static_cast<const TriangleRec *>(tris), n_tris, {}, format, ml, err))
+        return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
+    bool missing = false;
+    bool ok = build_accel_scene_level(mesh, n_mesh_nodes, ml, scene, n_scene_nodes, inst, n_inst, sl, err, &missing);
+    if(!ok && missing) {
+        std::vector<int32_t> roots;
+        for(size_t i = 0; i < n_inst; i++) roots.push_back(inst[i].meshIndex);
+        if(!build_accel_mesh_level(mesh, n_mesh_nodes, static_cast<const TriangleRec *>(tris), n_tris, roots, format, ml, err))
+            return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
+        ok = build_accel_scene_level(mesh, n_mesh_nodes, ml, scene, n_scene_nodes, inst, n_inst, sl, err);
+    }
+    if(!ok) return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
+    uint64_t counts[4];
+    if(!verify_accel_levels(mesh, n_mesh_nodes, ml, scene, n_scene_nodes, n_inst, sl, counts, err))
+        return fail(PT_ERR_STATE, "traversal layout check failed: " + err);
+    if(counts_out) memcpy(counts_out, counts, sizeof counts);
     return PT_OK;
 }
 

@@ -26,6 +26,13 @@ bool check_children(const BVHNodeInfo *nodes, size_t n, size_t i, const char *wh
     return true;
 }
 
+// child box inside the parent's box, coordinate by coordinate (false as soon as a NaN is involved)
+bool box_inside(const BVHNodeInfo &c, const BVHNodeInfo &p) {
+    for(int k = 0; k < 3; k++)
+        if(!(c.aa[k] >= p.aa[k]) || !(c.bb[k] <= p.bb[k])) return false;
+    return true;
+}
+
 float half_area(const BVHNodeInfo &n) {
     const float x = n.bb[0] - n.aa[0], y = n.bb[1] - n.aa[1], z = n.bb[2] - n.aa[2];
     return x * y + y * z + z * x;
@@ -191,6 +198,7 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
         return false;
     }
     out.n_tris = n_tris;
+    out.nested = true;
     std::vector<uint8_t> has_parent(n_mesh_nodes, 0);
     for(size_t i = 0; i < n_mesh_nodes; i++) {
         if(mesh[i].triangleIndex >= 0) {
@@ -251,6 +259,7 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
             if(!has_parent[ii]) fill_leaf((int32_t)ii, nullptr, nullptr);  // a one-triangle mesh
             continue;
         }
+        if(!box_inside(mesh[p.lsIndex], p) || !box_inside(mesh[p.rsIndex], p)) out.nested = false;
         TNode &t = out.slots[slot_of[ii]];
         set_box(t.lo0, t.hi0, mesh[p.lsIndex]);
         set_box(t.lo1, t.hi1, mesh[p.rsIndex]);
@@ -364,12 +373,14 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
         return scene[c].instanceIndex >= 0 ? make_ref(REF_INSTANCE, inst_base + 2u * (uint32_t)scene[c].instanceIndex)
                                            : make_ref(REF_SCENE_INNER, sinner_of[c]);
     };
+    out.nested = true;
     out.scene_nodes.assign(inst_base, TNode());
     memset(out.scene_nodes.data(), 0, out.scene_nodes.size() * sizeof(TNode));
     std::vector<int> sheight(n_scene_nodes, 1);
     for(size_t ii = n_scene_nodes; ii-- > 0;) {
         const BVHNodeInfo &p = scene[ii];
         if(p.instanceIndex >= 0) continue;
+        if(!box_inside(scene[p.lsIndex], p) || !box_inside(scene[p.rsIndex], p)) out.nested = false;
         TNode &t = out.scene_nodes[sinner_of[ii]];
         set_box(t.lo0, t.hi0, scene[p.lsIndex]);
         set_box(t.lo1, t.hi1, scene[p.rsIndex]);
@@ -400,6 +411,237 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
     // reference order: each level of a walk defers at most one sibling; ordered walk: three per wide level
     const int wide_stack = 3 * ((swide_height.empty() ? 0 : swide_height[0]) + max_wide_height);
     out.max_stack = std::max(sheight[0] + max_mesh_height, wide_stack);
+    return true;
+}
+
+namespace {
+
+// Child i of the wide node at `rec` as the ordered traversal sees it: reference and box
+// (NaN = that plane constrains nothing).
+void decode_child(const TNode *rec, bool quantised, int i, uint32_t &ref, float lo[3], float hi[3]) {
+    if(quantised) {
+        const QNode &q = *reinterpret_cast<const QNode *>(rec);
+        ref = q.c[i];
+        for(int a = 0; a < 3; a++) {
+            if(q.exponent[a] == 255) {
+                lo[a] = hi[a] = std::numeric_limits<float>::quiet_NaN();
+                continue;
+            }
+            const float s = std::ldexp(1.0f, (int)q.exponent[a] - 127);
+            lo[a] = std::fmaf((float)q.qlo[a][i], q.exponent[a] ? s : 0.0f, q.origin[a]);
+            hi[a] = std::fmaf((float)q.qhi[a][i], q.exponent[a] ? s : 0.0f, q.origin[a]);
+        }
+    } else {
+        const WNode &w = *reinterpret_cast<const WNode *>(rec);
+        const float *los[4] = {w.lo0, w.lo1, w.lo2, w.lo3}, *his[4] = {w.hi0, w.hi1, w.hi2, w.hi3};
+        ref = w.c[i];
+        for(int a = 0; a < 3; a++) {
+            lo[a] = los[i][a];
+            hi[a] = his[i][a];
+        }
+    }
+}
+
+// decoded box contains [aa, bb]?  (a NaN plane contains everything; a NaN in the reference box
+// can only be contained by a NaN plane)
+bool contains(const float lo[3], const float hi[3], const float aa[3], const float bb[3], uint64_t &unbounded) {
+    for(int a = 0; a < 3; a++) {
+        if(std::isnan(lo[a]) || std::isnan(hi[a])) {
+            unbounded++;
+            continue;
+        }
+        if(!(lo[a] <= aa[a]) || !(hi[a] >= bb[a])) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool verify_accel_levels(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const AccelMeshLevel &ml, const BVHNodeInfo *scene,
+                         size_t n_scene_nodes, size_t n_inst, const AccelSceneLevel &sl, uint64_t counts[4], std::string &err) {
+    for(int k = 0; k < 4; k++) counts[k] = 0;
+    if(ml.slots.empty()) {
+        err = "the mesh level no longer holds its slots";
+        return false;
+    }
+    // ---- mesh level
+    std::vector<int32_t> node_of_slot(ml.slots.size(), -1);
+    for(size_t n = 0; n < n_mesh_nodes; n++) {
+        if(ml.slot_of[n] >= ml.wide_base) {
+            err = "a binary slot lies in the wide area";
+            return false;
+        }
+        node_of_slot[ml.slot_of[n]] = (int32_t)n;
+    }
+    std::vector<int32_t> owner_of_wide(ml.slots.size(), -1);
+    for(size_t n = 0; n < n_mesh_nodes; n++)
+        if(ml.wide_of[n] != REF_NONE) {
+            if(ml.wide_of[n] < ml.wide_base || ml.wide_of[n] + ml.wide_stride > ml.slots.size() ||
+               (ml.wide_of[n] - ml.wide_base) % ml.wide_stride) {
+                err = "wide slot out of range";
+                return false;
+            }
+            owner_of_wide[ml.wide_of[n]] = (int32_t)n;
+            counts[0]++;
+        }
+    int deepest_mesh = 0;
+    for(size_t r = 0; r < n_mesh_nodes; r++) {
+        if(ml.wide_of[r] == REF_NONE) continue;
+        // triangles under r: binary walk
+        std::vector<int32_t> want, got, work{(int32_t)r};
+        while(!work.empty()) {
+            const int32_t n = work.back();
+            work.pop_back();
+            if(mesh[n].triangleIndex >= 0) want.push_back(mesh[n].triangleIndex);
+            else {
+                work.push_back(mesh[n].lsIndex);
+                work.push_back(mesh[n].rsIndex);
+            }
+        }
+        // ... and the wide walk, with the number of entries it leaves deferred
+        struct W { uint32_t slot; int pending; };
+        std::vector<W> wwork{{ml.wide_of[r], 0}};
+        while(!wwork.empty()) {
+            const W cur = wwork.back();
+            wwork.pop_back();
+            int present = 0;
+            for(int i = 0; i < 4; i++) {
+                uint32_t ref;
+                float lo[3], hi[3];
+                decode_child(&ml.slots[cur.slot], ml.quantised, i, ref, lo, hi);
+                if(ref == REF_NONE) {
+                    if(i < 2) {
+                        err = "a wide node lacks one of its first two children";
+                        return false;
+                    }
+                    continue;
+                }
+                present++;
+                const uint32_t kind = ref >> 30, slot = ref & REF_INDEX_MASK;
+                if(slot >= ml.slots.size()) {
+                    err = "a child reference leaves the mesh buffer";
+                    return false;
+                }
+                counts[2]++;
+                if(kind == REF_TRIANGLE) {
+                    if(slot >= ml.wide_base || node_of_slot[slot] < 0 || mesh[node_of_slot[slot]].triangleIndex < 0) {
+                        err = "a triangle reference does not name a leaf slot";
+                        return false;
+                    }
+                    const TLeaf &l = *reinterpret_cast<const TLeaf *>(&ml.slots[slot]);
+                    got.push_back((int32_t)l.triangle);
+                    if(!contains(lo, hi, l.parent_lo, l.parent_hi, counts[3])) {
+                        err = "a triangle child's box does not contain its parent's box";
+                        return false;
+                    }
+                } else if(kind == REF_MESH_INNER) {
+                    if(owner_of_wide[slot] < 0) {
+                        err = "an inner reference does not name a wide node";
+                        return false;
+                    }
+                    const BVHNodeInfo &m = mesh[owner_of_wide[slot]];
+                    if(!contains(lo, hi, m.aa, m.bb, counts[3])) {
+                        err = "an inner child's box does not contain the reference node's box";
+                        return false;
+                    }
+                } else {
+                    err = "a scene-level reference inside a mesh tree";
+                    return false;
+                }
+            }
+            // the walk into any child leaves at most the other present ones deferred
+            for(int i = 0; i < 4; i++) {
+                uint32_t ref;
+                float lo[3], hi[3];
+                decode_child(&ml.slots[cur.slot], ml.quantised, i, ref, lo, hi);
+                if(ref == REF_NONE) continue;
+                const int pending = cur.pending + present - 1;
+                deepest_mesh = std::max(deepest_mesh, pending);
+                if((ref >> 30) == REF_MESH_INNER) wwork.push_back({ref & REF_INDEX_MASK, pending});
+            }
+        }
+        std::sort(want.begin(), want.end());
+        std::sort(got.begin(), got.end());
+        if(want != got) {
+            err = "the wide tree under mesh node " + std::to_string(r) + " reaches other triangles than the binary tree";
+            return false;
+        }
+    }
+    // ---- scene level
+    const size_t inst_base = sl.header.inst_base, wide_base = inst_base + 2 * n_inst;
+    if(sl.scene_nodes.size() != inst_base || sl.instances.size() != n_inst) {
+        err = "scene level sizes are inconsistent";
+        return false;
+    }
+    counts[1] = sl.wide_nodes.size() / (ml.quantised ? 1 : 2);
+    int deepest_scene = 0;
+    if(scene[0].instanceIndex < 0) {
+        std::vector<int32_t> want, got, work{0};
+        while(!work.empty()) {
+            const int32_t n = work.back();
+            work.pop_back();
+            if(scene[n].instanceIndex >= 0) want.push_back(scene[n].instanceIndex);
+            else {
+                work.push_back(scene[n].lsIndex);
+                work.push_back(scene[n].rsIndex);
+            }
+        }
+        struct W { uint32_t slot; int pending; };
+        if((sl.header.wide_root_ref >> 30) != REF_SCENE_INNER) {
+            err = "the scene's wide root is not a scene node";
+            return false;
+        }
+        std::vector<W> wwork{{sl.header.wide_root_ref & REF_INDEX_MASK, 0}};
+        while(!wwork.empty()) {
+            const W cur = wwork.back();
+            wwork.pop_back();
+            if(cur.slot < wide_base || cur.slot - wide_base + (ml.quantised ? 1 : 2) > sl.wide_nodes.size()) {
+                err = "a scene-level wide reference leaves the scene buffer";
+                return false;
+            }
+            int present = 0;
+            uint32_t refs[4];
+            for(int i = 0; i < 4; i++) {
+                float lo[3], hi[3];
+                decode_child(&sl.wide_nodes[cur.slot - wide_base], ml.quantised, i, refs[i], lo, hi);
+                if(refs[i] == REF_NONE) continue;
+                present++;
+                counts[2]++;
+                const uint32_t kind = refs[i] >> 30, slot = refs[i] & REF_INDEX_MASK;
+                if(kind == REF_INSTANCE) {
+                    if(slot < inst_base || slot >= wide_base || (slot - inst_base) % 2) {
+                        err = "an instance reference does not name an instance record";
+                        return false;
+                    }
+                    const InstAccel &ia = sl.instances[(slot - inst_base) / 2];
+                    got.push_back((int32_t)((slot - inst_base) / 2));
+                    if(!contains(lo, hi, ia.world_lo, ia.world_hi, counts[3])) {
+                        err = "an instance child's box does not contain the scene leaf box";
+                        return false;
+                    }
+                } else if(kind != REF_SCENE_INNER) {
+                    err = "a mesh-level reference inside the scene tree";
+                    return false;
+                }
+            }
+            for(int i = 0; i < 4; i++) {
+                if(refs[i] == REF_NONE) continue;
+                const int pending = cur.pending + present - 1;
+                deepest_scene = std::max(deepest_scene, pending);
+                if((refs[i] >> 30) == REF_SCENE_INNER) wwork.push_back({refs[i] & REF_INDEX_MASK, pending});
+            }
+        }
+        std::sort(want.begin(), want.end());
+        std::sort(got.begin(), got.end());
+        if(want != got) {
+            err = "the wide scene tree reaches other instances than the binary tree";
+            return false;
+        }
+    }
+    if(deepest_mesh + deepest_scene > sl.max_stack) {
+        err = "max_stack " + std::to_string(sl.max_stack) + " is below the deepest walk " + std::to_string(deepest_mesh + deepest_scene);
+        return false;
+    }
     return true;
 }
 

@@ -21,6 +21,9 @@ struct AccelMeshLevel {
     uint32_t wide_base = 0;             // first wide-node slot
     uint32_t wide_stride = 2;           // slots per wide node: 2 (WNode) or 1 (QNode)
     bool quantised = false;
+    // every child box lies inside its parent's (what the reference's builder produces, and what
+    // lets the ordered traversal skip or loosen the tests of ancestors)
+    bool nested = true;
     size_t n_tris = 0;
 };
 
@@ -32,6 +35,7 @@ struct AccelSceneLevel {
     std::vector<TNode> wide_nodes;      // WNodes (two slots each) or QNodes after the instances, as raw slots
     SceneHeader header;
     int max_stack = 0;  // upper bound of deferred entries one ray can hold (scene + mesh height)
+    bool nested = true; // as in the mesh level, for the scene tree
 };
 
 // Both return false and set err when the buffers are inconsistent.
@@ -44,5 +48,14 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
 bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const AccelMeshLevel &ml, const BVHNodeInfo *scene,
                              size_t n_scene_nodes, const InstanceInfo *inst, size_t n_inst, AccelSceneLevel &out,
                              std::string &err, bool *missing_root = nullptr);
+
+// Independent check of the two levels (host only, meant for tests and for debugging a scene
+// the kernels disagree on): every wide tree reaches exactly the triangles / instances its
+// binary tree reaches, every child box as the kernel decodes it contains the reference's box
+// (for a triangle: its parent's), references stay inside the buffers, and max_stack bounds
+// the deferred entries of the deepest walk.  counts: {wide mesh nodes, wide scene nodes,
+// child boxes checked, planes that decode to "unbounded"}.
+bool verify_accel_levels(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const AccelMeshLevel &ml, const BVHNodeInfo *scene,
+                         size_t n_scene_nodes, size_t n_inst, const AccelSceneLevel &sl, uint64_t counts[4], std::string &err);
 
 }  // namespace rta

@@ -235,7 +235,8 @@ class PathTracingPass:
         check(lib.pt_pass_stats(self.h, C.byref(s), int(reset)))
         return dict(samples=int(s.samples), rays_extend=int(s.rays_extend), rays_shadow=int(s.rays_shadow),
                     draws=int(s.draws), rays_retraced=int(s.rays_retraced), mesh_level_builds=int(s.mesh_level_builds),
-                    scene_level_builds=int(s.scene_level_builds), debug=[int(x) for x in s.debug])
+                    scene_level_builds=int(s.scene_level_builds), debug=[int(x) for x in s.debug],
+                    reference_order_forced=int(s.reference_order_forced))
 
     def set_traversal(self, mode):
         """0 = ordered traversal with exact fallback (default), 1 = reference order only."""

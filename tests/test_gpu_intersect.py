@@ -26,7 +26,7 @@ def test_casa_random_rays(casa, oracle_mod, gpu_ctx):
     p = device.PathTracingPass(gpu_ctx, 16, 16)
     p.bind_scene(sb)
     hits = device.trace_rays(p, rays)
-    p.stats()
+    assert p.stats()["reference_order_forced"] == 0
     ref, cnt = oracle_mod.OracleScene(casa).intersect(rays)
     assert 0.2 < (ref["triangle"] >= 0).mean() < 0.3
     _check(hits, ref)
@@ -55,6 +55,41 @@ def test_both_wide_node_formats(casa, oracle_mod, gpu_ctx, fmt):
     assert p.stats()["mesh_level_builds"] == builds + 1
     with pytest.raises(Exception):
         p.set_wide_nodes(2)
+    p.destroy()
+    sb.release()
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_non_finite_and_huge_node_boxes(casa, oracle_mod, gpu_ctx, fmt):
+    """Boxes with NaN, infinite or overflowing coordinates: the reference's min/max drop NaNs
+    (pathtracing.glsl:208-221), so such a box passes more rays; results must still agree."""
+    import copy
+    from raytracing_amd import device
+    sd = copy.copy(casa)
+    nodes = casa.mesh_nodes.copy()
+    inner = np.flatnonzero(nodes["tri"] < 0)
+    rng = np.random.default_rng(3)
+    pick = rng.choice(inner[19:], 400, replace=False)
+    nodes["aa"][pick[:100], 0] = np.nan
+    nodes["bb"][pick[100:200], 1] = np.inf
+    nodes["aa"][pick[200:300], 2] = -3e38
+    nodes["bb"][pick[200:300], 2] = 3e38
+    nodes["bb"][pick[300:350], :3] = np.nan
+    nodes["bb"][pick[350:], :3] -= 0.25 * (nodes["bb"][pick[350:], :3] - nodes["aa"][pick[350:], :3])  # shrunk: children stick out
+    sd.mesh_nodes = nodes
+    lo, hi = casa.world_box()
+    rays = random_rays(lo, hi, 1 << 18, 41)
+    sb = device.SceneBuffers(gpu_ctx, sd)
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    p.bind_scene(sb)
+    p.set_wide_nodes(fmt)
+    hits = device.trace_rays(p, rays)
+    ref, _ = oracle_mod.OracleScene(sd).intersect(rays)
+    assert (ref["triangle"] >= 0).mean() > 0.1
+    _check(hits, ref)
+    # such buffers are traced in the reference's order: the ordered traversal relies on nesting
+    st = p.stats()
+    assert st["reference_order_forced"] == 1 and st["rays_retraced"] == 0
     p.destroy()
     sb.release()
 

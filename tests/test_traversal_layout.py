@@ -1,0 +1,109 @@
+"""Host re-layout of the reference's BVH buffers into the records the ordered traversal
+reads (four-wide nodes, full precision or quantised).  pt_host_check_traversal_layout builds
+them on the CPU and verifies them independently: same triangles / instances reachable as in
+the reference's binary trees (src/ResourceManager.cpp:95-198), every decoded child box contains
+the reference's, references in range, stack bound sufficient."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracing_amd import scene
+from raytracing_amd._capi import lib
+
+
+def check_layout(sd, fmt, mesh_nodes=None, instances=None):
+    mesh_nodes = sd.mesh_nodes if mesh_nodes is None else mesh_nodes
+    instances = sd.instances if instances is None else instances
+    counts = (C.c_uint64 * 4)()
+    rc = lib.pt_host_check_traversal_layout(mesh_nodes.ctypes.data, len(mesh_nodes), sd.triangles.ctypes.data, len(sd.triangles),
+                                            sd.scene_nodes.ctypes.data, len(sd.scene_nodes), instances.ctypes.data,
+                                            len(instances), fmt, counts)
+    return rc, [int(c) for c in counts], lib.pt_last_error().decode()
+
+
+@pytest.mark.parametrize("fmt", [0, 1, -1])
+def test_casa_layout(casa, fmt):
+    rc, counts, err = check_layout(casa, fmt)
+    assert rc == 0, err
+    n_inner = int((casa.mesh_nodes["tri"] < 0).sum())
+    # collapsing to four children: between a third and all of the inner nodes remain
+    assert n_inner / 3 <= counts[0] <= n_inner
+    assert counts[1] >= 1 and counts[2] > len(casa.triangles)
+    assert counts[3] == 0  # every plane of casa is finite and fits its grid
+
+
+def _random_mesh(rng, n, scale=1.0, offset=(0, 0, 0)):
+    t = np.zeros((n, 24), np.float32)
+    c = rng.uniform(-1, 1, (n, 1, 3)) * scale
+    t[:, :9] = (c + rng.normal(0, 0.05 * scale, (n, 3, 3)) + np.asarray(offset, np.float32)).reshape(n, 9)
+    t[:, 9:18] = np.tile([0, 0, 1], 3)
+    return t
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_hostile_geometry(fmt):
+    """Scales from 1e-6 to 1e6, a mesh 1e7 away from the origin (one ulp there is 1.0), flat and
+    duplicated triangles, a one-triangle mesh, a two-triangle mesh."""
+    rng = np.random.default_rng(5)
+    sb = scene.SceneBuilder()
+    meshes = [_random_mesh(rng, 500, 1e-6), _random_mesh(rng, 500, 1e6), _random_mesh(rng, 300, 1.0, (1e7, -1e7, 3e6)),
+              _random_mesh(rng, 1), _random_mesh(rng, 2)]
+    flat = _random_mesh(rng, 200)
+    flat[:, 2:9:3] = 0.25            # all in the plane z = 0.25
+    flat[100:] = flat[:100]          # duplicates
+    meshes.append(flat)
+    for m in meshes:
+        sb.add_instance(sb.add_mesh(m))
+    sb.add_instance(0, scene.transform_matrix(position=(3, 0, 0), scale=(1e3, 1e3, 1e3)))
+    sd = sb.finish()
+    rc, counts, err = check_layout(sd, fmt)
+    assert rc == 0, err
+    assert counts[3] == 0
+
+
+def test_non_finite_boxes_decode_to_unbounded(casa):
+    """A NaN / infinite reference box cannot be put on a grid: the quantised node lets every ray
+    through on that axis instead (the exact tests further down decide)."""
+    nodes = casa.mesh_nodes.copy()
+    inner = np.flatnonzero(nodes["tri"] < 0)
+    rng = np.random.default_rng(1)
+    pick = rng.choice(inner[100:], 90, replace=False)   # (a box that is expanded away leaves no trace: take many)
+    nodes["aa"][pick[:30], 0] = np.nan
+    nodes["bb"][pick[30:60], 1] = np.inf
+    nodes["aa"][pick[60:], 2] = -3e38
+    nodes["bb"][pick[60:], 2] = 3e38   # finite, but the extent overflows every grid
+    rc, counts, err = check_layout(casa, 1, mesh_nodes=nodes)
+    assert rc == 0, err
+    assert counts[3] > 0
+    rc, counts, err = check_layout(casa, 0, mesh_nodes=nodes)
+    assert rc == 0, err
+
+
+def test_instances_that_start_inside_a_tree(casa):
+    """An instance may name any node of the mesh BVH as its root; the wide trees are built for
+    those nodes on demand."""
+    inst = casa.instances.copy()
+    inner = np.flatnonzero(casa.mesh_nodes["tri"] < 0)
+    leaf = np.flatnonzero(casa.mesh_nodes["tri"] >= 0)
+    inst["meshIndex"][0] = inner[len(inner) // 2]
+    inst["meshIndex"][1] = leaf[len(leaf) // 2]
+    for fmt in (0, 1):
+        rc, counts, err = check_layout(casa, fmt, instances=inst)
+        assert rc == 0, err
+
+
+def test_malformed_buffers_are_refused(casa):
+    nodes = casa.mesh_nodes.copy()
+    inner = np.flatnonzero(nodes["tri"] < 0)
+    nodes["ls"][inner[5]] = inner[5]          # a cycle
+    rc, _, err = check_layout(casa, 1, mesh_nodes=nodes)
+    assert rc != 0 and "invalid child" in err
+    nodes = casa.mesh_nodes.copy()
+    nodes["tri"][np.flatnonzero(nodes["tri"] >= 0)[0]] = len(casa.triangles)
+    rc, _, err = check_layout(casa, 1, mesh_nodes=nodes)
+    assert rc != 0 and "out of range" in err
+    inst = casa.instances.copy()
+    inst["meshIndex"][0] = len(casa.mesh_nodes)
+    rc, _, err = check_layout(casa, 1, instances=inst)
+    assert rc != 0 and "out of range" in err
