@@ -54,18 +54,17 @@ struct alignas(128) WNode {
 static_assert(sizeof(WNode) == 128, "wide traversal node is 128 bytes");
 
 // The same four children in 64 bytes (the default: half the loads per visit outweighs the
-// decoding): child boxes on a grid of 256 steps per axis laid over the
-// node's box, rounded outwards, so that decoding (fma(step, scale, origin), one rounding) never
-// yields a box smaller than the exact one.  scale = 2^(e - 127) from the exponent byte e; e = 255
-// gives an infinite scale, every plane decodes to NaN and the slab test lets every ray through
+// decoding): child boxes on a grid of 256 steps per axis laid over the node's box (lo <= hi on
+// every axis), rounded outwards, so that decoding (fma(step, scale, origin), one rounding)
+// never yields a box smaller than the exact one.  scale is a power of two; an infinite scale
+// makes every plane of that axis decode to NaN, which the slab test ignores: every ray passes
 // (used when a coordinate is not finite or the extent exceeds the grid).
 struct alignas(64) QNode {
     float origin[3];
-    uint8_t exponent[3], pad0;
+    float scale[3];
     uint32_t c[4];
     uint8_t qlo[3][4];  // [axis][child]
     uint8_t qhi[3][4];
-    uint32_t pad1[2];
 };
 static_assert(sizeof(QNode) == 64, "quantised wide node is 64 bytes");
 

@@ -14,7 +14,8 @@
 // So this kernel is free to visit nodes in any order and to cull with cheaper arithmetic,
 // as long as
 //   (1) culling is conservative: boxes are tested with a per-ray reciprocal and the
-//       comparisons are relaxed by 1e-6, three times the arithmetic's error;
+//       comparisons are relaxed by 1e-6, three times the arithmetic's error; boxes may be
+//       larger than the reference's (quantised nodes round outwards) but never smaller;
 //   (2) a hit is accepted only for a candidate: the parent box (and, where a scene node
 //       hands over to an instance, the scene leaf box) is re-tested with the reference's
 //       exact IEEE-division slab test whenever the relaxed test did not pass with the same
@@ -26,11 +27,18 @@
 //       the reference-order kernel (trace_core.h), which is exact by construction.
 // The triangle test itself is the reference's Moller-Trumbore, bit for bit.
 // Occlusion queries ("is there any candidate hit") have no order dependence at all.
+// (The host refuses this kernel for buffers whose child boxes are not inside their parents'.)
 //
-// Loop shape: the kernel is bound by the latency of dependent gathers, not by arithmetic,
-// so every lane issues exactly ONE 64-byte fetch per iteration, whatever it is about to
-// visit (inner node, triangle leaf and instance record are all 64-byte records), the wave
-// waits once, and only then the three kinds are told apart.
+// Because only the parent box of a triangle and the scene leaf box of an instance matter
+// exactly, the boxes in between need not be visited one by one: the kernel walks the
+// reference's binary trees collapsed to FOUR children per node (device_types.h: QNode, 64
+// bytes with boxes on a 256-step grid, or WNode, 128 bytes with the fp32 boxes), which halves
+// the dependent fetches per ray.  A triangle child carries its reference parent's box.
+//
+// Loop shape: every lane issues the loads of ONE record per iteration, whatever it is about
+// to visit (wide node, triangle leaf, instance record), the wave waits once, and only then the
+// three kinds are told apart.  Children that pass are sorted by entry distance; the nearest
+// is visited next, the others are deferred so that they come back nearest first.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_types.h"
@@ -253,24 +261,30 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                 float t0, t1, t2, t3, x0, x1, x2, x3;
                 unsigned r0, r1, r2, r3;
                 if(QUANT) {
-                    // q0 = origin, exponent bytes; q1 = references; q2 = lo.x, lo.y, lo.z, hi.x of the
-                    // four children (one byte each); q3.xy = hi.y, hi.z
-                    const unsigned eb = __float_as_uint(q0.w);
-                    const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23);
-                    const float sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
-                    const unsigned lx = __float_as_uint(q2.x), ly = __float_as_uint(q2.y), lz = __float_as_uint(q2.z);
-                    const unsigned hx = __float_as_uint(q2.w), hy = __float_as_uint(q3.x), hz = __float_as_uint(q3.y);
-#define RT_Q(packed, i, scale, org) __builtin_fmaf((float)(((packed) >> (8 * (i))) & 0xFFu), scale, org)
-#define RT_QBOX(i, T_IN, T_OUT) \
-    slab_range(RT_Q(lx, i, sx, q0.x), RT_Q(ly, i, sy, q0.y), RT_Q(lz, i, sz, q0.z), RT_Q(hx, i, sx, q0.x), RT_Q(hy, i, sy, q0.y), \
-               RT_Q(hz, i, sz, q0.z), cox, coy, coz, cix, ciy, ciz, T_IN, T_OUT)
+                    // q0 = origin.xyz, scale.x; q1 = scale.yz, references 0 1; q2 = references 2 3, then
+                    // lo.x, lo.y of the four children (one byte each); q3 = lo.z, hi.x, hi.y, hi.z
+                    const float sx = q0.w, sy = q1.x, sz = q1.y;
+                    const unsigned lx = __float_as_uint(q2.z), ly = __float_as_uint(q2.w), lz = __float_as_uint(q3.x);
+                    const unsigned hx = __float_as_uint(q3.y), hy = __float_as_uint(q3.z), hz = __float_as_uint(q3.w);
+                    // The host stores lo <= hi on every axis, so the sign of the direction tells
+                    // which plane is met first: one select per axis for all four children instead
+                    // of a min and a max per child and axis.  A NaN plane distance (0 * inf)
+                    // drops out of max3 / min3 and only lets more rays through.
+                    const bool ngx = (int)__float_as_uint(cix) < 0, ngy = (int)__float_as_uint(ciy) < 0, ngz = (int)__float_as_uint(ciz) < 0;
+                    const unsigned nx = ngx ? hx : lx, fx = ngx ? lx : hx;
+                    const unsigned ny = ngy ? hy : ly, fy = ngy ? ly : hy;
+                    const unsigned nz = ngz ? hz : lz, fz = ngz ? lz : hz;
+#define RT_Q(packed, i, scale, org, o, inv) ((__builtin_fmaf((float)(((packed) >> (8 * (i))) & 0xFFu), scale, org) - (o)) * (inv))
+#define RT_QBOX(i, T_IN, T_OUT)                                                                                              \
+    T_IN = fmaxf(0.0f, fmaxf(fmaxf(RT_Q(nx, i, sx, q0.x, cox, cix), RT_Q(ny, i, sy, q0.y, coy, ciy)), RT_Q(nz, i, sz, q0.z, coz, ciz))); \
+    T_OUT = fminf(RT_INF, fminf(fminf(RT_Q(fx, i, sx, q0.x, cox, cix), RT_Q(fy, i, sy, q0.y, coy, ciy)), RT_Q(fz, i, sz, q0.z, coz, ciz)))
                     RT_QBOX(0, t0, x0);
                     RT_QBOX(1, t1, x1);
                     RT_QBOX(2, t2, x2);
                     RT_QBOX(3, t3, x3);
 #undef RT_QBOX
 #undef RT_Q
-                    r0 = __float_as_uint(q1.x); r1 = __float_as_uint(q1.y); r2 = __float_as_uint(q1.z); r3 = __float_as_uint(q1.w);
+                    r0 = __float_as_uint(q1.z); r1 = __float_as_uint(q1.w); r2 = __float_as_uint(q2.x); r3 = __float_as_uint(q2.y);
                 } else {
                     slab_range(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, x0);
                     slab_range(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, cox, coy, coz, cix, ciy, ciz, t1, x1);

@@ -44,7 +44,7 @@ float half_area(const BVHNodeInfo &n) {
 // make the references; a leaf child carries its reference parent's box when
 // leaf_box_of_parent, else its own.  Wide node k gets slot slot_base + 2 k.
 // Child boxes of one wide node on the node's 256-step grid, rounded outwards as decoded:
-// fmaf(step, 2^(e - 127), origin) <= lo and >= hi in fp32.
+// fmaf(step, scale, origin) <= lo and >= hi in fp32, scale = 2^(e - 127).
 void quantise_node(const uint32_t refs[4], const BVHNodeInfo *const boxes[4], QNode &q) {
     memset(&q, 0, sizeof q);
     for(int i = 0; i < 4; i++) q.c[i] = refs[i];
@@ -75,12 +75,13 @@ void quantise_node(const uint32_t refs[4], const BVHNodeInfo *const boxes[4], QN
             }
         }
         q.origin[a] = finite ? o : 0.0f;
-        q.exponent[a] = (uint8_t)e;
+        q.scale[a] = e == 255 ? std::numeric_limits<float>::infinity() : std::ldexp(1.0f, e - 127);
         if(e == 255) continue;  // every plane decodes to NaN: the axis constrains nothing
-        const float s = std::ldexp(1.0f, e - 127);
+        const float s = q.scale[a];
         for(int i = 0; i < 4; i++) {
             if(!boxes[i]) continue;
-            const float l = boxes[i]->aa[a], h = boxes[i]->bb[a];
+            // (the slab test treats its two planes alike, so an inverted box is stored the right way round)
+            const float l = std::min(boxes[i]->aa[a], boxes[i]->bb[a]), h = std::max(boxes[i]->aa[a], boxes[i]->bb[a]);
             int ql = (int)std::floor(((double)l - (double)o) / (double)s);
             ql = std::max(0, std::min(255, ql));
             while(ql > 0 && std::fmaf((float)ql, s, o) > l) ql--;
@@ -423,13 +424,8 @@ void decode_child(const TNode *rec, bool quantised, int i, uint32_t &ref, float 
         const QNode &q = *reinterpret_cast<const QNode *>(rec);
         ref = q.c[i];
         for(int a = 0; a < 3; a++) {
-            if(q.exponent[a] == 255) {
-                lo[a] = hi[a] = std::numeric_limits<float>::quiet_NaN();
-                continue;
-            }
-            const float s = std::ldexp(1.0f, (int)q.exponent[a] - 127);
-            lo[a] = std::fmaf((float)q.qlo[a][i], q.exponent[a] ? s : 0.0f, q.origin[a]);
-            hi[a] = std::fmaf((float)q.qhi[a][i], q.exponent[a] ? s : 0.0f, q.origin[a]);
+            lo[a] = std::fmaf((float)q.qlo[a][i], q.scale[a], q.origin[a]);  // 0 * inf = NaN: unbounded
+            hi[a] = std::fmaf((float)q.qhi[a][i], q.scale[a], q.origin[a]);
         }
     } else {
         const WNode &w = *reinterpret_cast<const WNode *>(rec);
@@ -450,7 +446,7 @@ bool contains(const float lo[3], const float hi[3], const float aa[3], const flo
             unbounded++;
             continue;
         }
-        if(!(lo[a] <= aa[a]) || !(hi[a] >= bb[a])) return false;
+        if(!(lo[a] <= std::min(aa[a], bb[a])) || !(hi[a] >= std::max(aa[a], bb[a]))) return false;
     }
     return true;
 }

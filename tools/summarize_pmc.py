@@ -24,6 +24,7 @@ for f in glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True):
         if sub and sub not in k:
             continue
         k = k.replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1]
+        k = k.split("<")[0]  # instantiations of one kernel template count together
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k][r["Counter_Name"]] += 1
 for k in tot:
