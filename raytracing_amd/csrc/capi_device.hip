@@ -875,9 +875,9 @@ int pt_pass_draw(pt_pass *p) {
             launch_extend_fast(s, fsc, p->trace_blocks, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, qr,
                                cnt + CNT_REDO + dep);
             // near-ties in t: decided by the reference-order traversal
-            launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep);
+            launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep, true);
         } else {
-            launch_extend(s, sc, p->trace_blocks, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep);
+            launch_extend(s, sc, p->trace_blocks, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, false);
         }
     };
     if(!raster_first) extend(0, q_in);  // with RasterizaionFor1st the first hit comes from the raster images
@@ -897,8 +897,9 @@ int pt_pass_draw(pt_pass *p) {
             if(merged) {
                 ScopedTimer t(p, K_TRACE);
                 launch_path_trace_fast(s, fsc, p->trace_blocks, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, dp.rays,
-                                       dp.hits, dp.shadow, (int)npix, cnt + CNT_NEXT + 2 * dep + 1, qr, cnt + CNT_REDO + dep + 1);
-                launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep + 1, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep + 1);
+                                       dp.hits, dp.shadow, (int)npix, cnt + CNT_NEXT + 2 * dep + 1, qr, cnt + CNT_REDO + dep + 1, dp.thr,
+                                       dp.acc, dp.stats + 2);
+                launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep + 1, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep + 1, true);
             } else {
                 {
                     ScopedTimer t(p, K_SHADOW);
@@ -911,8 +912,10 @@ int pt_pass_draw(pt_pass *p) {
                 }
                 extend(dep + 1, q_out);
             }
-            ScopedTimer t(p, K_OTHER);
-            launch_shadow_apply(s, dp, qs, cnt + CNT_SHADOW + dep);
+            if(!merged) {  // (the merged launch applies each light sample where its occlusion query ends)
+                ScopedTimer t(p, K_OTHER);
+                launch_shadow_apply(s, dp, qs, cnt + CNT_SHADOW + dep);
+            }
         }
         q_in = q_out;
     }

@@ -64,7 +64,7 @@ void launch_intersect_fast(hipStream_t s, const FastScene &sc, int blocks, const
                            pt_hit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count);
 // extend stage: rays[queue[q]] -> hits[queue[q]] for q < *count (queue == nullptr: q itself)
 void launch_extend(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
-                   const PathRay *rays, PathHit *hits, unsigned *next_counter);
+                   const PathRay *rays, PathHit *hits, unsigned *next_counter, bool second_pass);
 void launch_extend_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                         const PathRay *rays, PathHit *hits, unsigned *next_counter, unsigned *redo,
                         unsigned *redo_count);
@@ -77,7 +77,8 @@ void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const un
 
 void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue_e, const unsigned *count_e,
                             const unsigned *queue_s, const unsigned *count_s, const PathRay *rays, PathHit *hits,
-                            ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo, unsigned *redo_count);
+                            ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo, unsigned *redo_count,
+                            const PathThroughput *thr, PathAccum *acc, unsigned long long *shadow_rays_stat);
 void launch_generate(hipStream_t s, const DrawParams &dp);
 // shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to
 // queue_out and paths with pending light samples to shadow_queue.

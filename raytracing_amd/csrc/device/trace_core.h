@@ -145,6 +145,14 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                     wox = o[0]; woy = o[1]; woz = o[2];
                     wdx = d[0]; wdy = d[1]; wdz = d[2];
                     best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
+                    // A ray the ordered traversal could not decide comes with that pass's closest
+                    // distance.  What the reference returns lies within 2e-4 of it, and a subtree
+                    // whose box is entered beyond 1.001 times that distance can neither hold the
+                    // answer nor prune a subtree that does (its hits are farther than every such
+                    // subtree's entry), so it is skipped: start from that bound instead of infinity.
+                    const float provisional = src.bound(idx);
+                    if(provisional < RT_INF)
+                        best.t = provisional * 1.001f + 8e-6f * (fabsf(wox) + fabsf(woy) + fabsf(woz) + sc.hdr.extent);
                     active = true;
                     sp = 0;
                     float t0;
@@ -173,6 +181,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                     tn = __uint_as_float(e.y);
                     have = true;
                 } else {
+                    if(best.tri < 0) best.t = RT_INF;  // (a bound is not a hit)
                     sink.store(ray_idx, best);
                     active = false;
                 }

@@ -20,6 +20,8 @@ namespace {
 struct RaySource {
     const float *rays;
     const unsigned *redo;
+    const pt_hit *provisional;  // with redo: what the ordered pass found for those rays
+    __device__ float bound(unsigned idx) const { return redo ? provisional[redo[idx]].t : RT_INF; }
     __device__ bool load(unsigned idx, float o[3], float d[3], bool &any_hit) const {
         const unsigned r = redo ? redo[idx] : idx;
         // streamed once: keep it from displacing the scene in the caches
@@ -51,8 +53,8 @@ struct HitSinkFast {
     pt_hit *hits;
     unsigned *redo, *redo_count;
     __device__ void store(unsigned idx, const LaneHit &h, bool ambiguous) const {
+        write_hit(hits, idx, h);  // (provisional for an ambiguous ray: bounds its second pass)
         if(ambiguous) redo[atomicAdd(redo_count, 1u)] = idx;
-        else write_hit(hits, idx, h);
     }
 };
 
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void intersect_kernel(TraceScene sc, c
                                                                 const unsigned *redo, const unsigned *redo_count,
                                                                 pt_hit *hits, unsigned *next_counter) {
     __shared__ uint2 s_stack[LDS_STACK * TRACE_BLOCK];
-    RaySource src{rays, redo};
+    RaySource src{rays, redo, hits};
     HitSink sink{hits, redo};
     trace_persistent(sc, src, sink, next_counter, redo ? *redo_count : n, s_stack);
 }
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void intersect_fast_kernel(
                                                                     pt_hit *hits, unsigned *next_counter,
                                                                     unsigned *redo, unsigned *redo_count) {
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
-    RaySource src{rays, nullptr};
+    RaySource src{rays, nullptr, nullptr};
     HitSinkFast sink{hits, redo, redo_count};
     trace_ordered<QUANT>(sc, src, sink, next_counter, n, s_stack);
 }
@@ -79,6 +81,8 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void intersect_fast_kernel(
 struct ExtendSource {
     const unsigned *queue;
     const PathRay *rays;
+    const PathHit *provisional;  // second pass over the ordered traversal's undecided rays: its hits, else null
+    __device__ float bound(unsigned idx) const { return provisional ? provisional[queue ? queue[idx] : idx].t : RT_INF; }
     __device__ bool load(unsigned idx, float o[3], float d[3], bool &any_hit) const {
         const unsigned px = queue ? queue[idx] : idx;
         const float4 *p = reinterpret_cast<const float4 *>(rays + px);
@@ -105,16 +109,17 @@ struct ExtendSinkFast {
     unsigned *redo, *redo_count;  // redo lists PIXEL slots, so the reference-order extend can take it as its queue
     __device__ void store(unsigned idx, const LaneHit &h, bool ambiguous) const {
         const unsigned px = queue ? queue[idx] : idx;
+        write_path_hit(hits, px, h);  // (provisional for an ambiguous ray: bounds its second pass)
         if(ambiguous) redo[atomicAdd(redo_count, 1u)] = px;
-        else write_path_hit(hits, px, h);
     }
 };
 
+// second_pass: the queue lists the rays the ordered kernel left undecided, with its hits in place
 __global__ __launch_bounds__(TRACE_BLOCK) void extend_kernel(TraceScene sc, const unsigned *queue,
                                                              const unsigned *count, const PathRay *rays,
-                                                             PathHit *hits, unsigned *next_counter) {
+                                                             PathHit *hits, unsigned *next_counter, bool second_pass) {
     __shared__ uint2 s_stack[LDS_STACK * TRACE_BLOCK];
-    ExtendSource src{queue, rays};
+    ExtendSource src{queue, rays, second_pass ? hits : nullptr};
     ExtendSink sink{queue, hits};
     trace_persistent(sc, src, sink, next_counter, *count, s_stack);
 }
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_fast_kernel(Fas
                                                                  PathHit *hits, unsigned *next_counter,
                                                                  unsigned *redo, unsigned *redo_count) {
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
-    ExtendSource src{queue, rays};
+    ExtendSource src{queue, rays, nullptr};
     ExtendSinkFast sink{queue, hits, redo, redo_count};
     trace_ordered<QUANT>(sc, src, sink, next_counter, *count, s_stack);
 }
@@ -140,6 +145,7 @@ struct ShadowSource {
     const PathRay *rays;
     const ShadowEntry *shadow;
     int n_shadow, npix;
+    __device__ float bound(unsigned) const { return RT_INF; }  // occlusion queries have no second pass
     __device__ bool load(unsigned idx, float o[3], float d[3], bool &any_hit) const {
         const unsigned q = idx / (unsigned)n_shadow, k = idx - q * (unsigned)n_shadow;
         const unsigned px = queue[q];
@@ -192,7 +198,8 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_fast_kernel(Fas
 
 // ---- shadow rays of vertex d and extend rays of vertex d+1 in ONE launch ---------------------
 // Both are produced by shade(d) and neither reads what the other writes (shadow rays start at
-// the origin of the new ray, extend writes hits, shadow writes its own flags), so they share
+// the origin of the new ray, extend writes hits, a visible light sample goes straight into its
+// path's accumulator), so they share
 // one persistent launch: work item idx < n_extend is an extend ray, the rest are shadow rays.
 // Halves the number of trace launches per draw; late vertices carry few rays and each launch
 // costs at least the latency of its longest ray.
@@ -204,9 +211,33 @@ struct PathSource {
         return idx < n_extend ? e.load(idx, o, d, any_hit) : s.load(idx - n_extend, o, d, any_hit);
     }
 };
+// The sky-only form of shadow_apply_kernel (path_kernels.hip), done where the occlusion query
+// ends: one pending sample per path, so nobody else touches that path's accumulator meanwhile.
+struct ShadowApplySink {
+    const unsigned *queue;
+    const ShadowEntry *shadow;
+    const PathThroughput *thr;
+    PathAccum *acc;
+    __device__ void store(unsigned idx, const LaneHit &h) const {
+        const unsigned px = queue[idx];
+        const float4 *e = reinterpret_cast<const float4 *>(shadow + px);
+        const float4 e0 = e[0], e1 = e[1];
+        if(!(h.tri < 0 || h.t * h.t > e0.w)) return;  // occluded
+        const float4 t0 = *reinterpret_cast<const float4 *>(thr + px);
+        PathAccum *a = acc + px;
+        a->gi[0] = a->gi[0] + t0.x * e1.x;
+        a->gi[1] = a->gi[1] + t0.y * e1.y;
+        a->gi[2] = a->gi[2] + t0.z * e1.z;
+        if(__float_as_uint(e1.w) & 2u) {
+            a->di[0] = e1.x;
+            a->di[1] = e1.y;
+            a->di[2] = e1.z;
+        }
+    }
+};
 struct PathSink {
     ExtendSinkFast e;
-    ShadowSink s;
+    ShadowApplySink s;
     unsigned n_extend;
     __device__ void store(unsigned idx, const LaneHit &h, bool ambiguous) const {
         if(idx < n_extend) e.store(idx, h, ambiguous);
@@ -218,11 +249,12 @@ template <bool QUANT>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel(
     FastScene sc, const unsigned *queue_e, const unsigned *count_e, const unsigned *queue_s, const unsigned *count_s,
     const PathRay *rays, PathHit *hits, ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo,
-    unsigned *redo_count) {
+    unsigned *redo_count, const PathThroughput *thr, PathAccum *acc, unsigned long long *shadow_rays_stat) {
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
     const unsigned n_e = *count_e, n_s = *count_s;
-    PathSource src{ExtendSource{queue_e, rays}, ShadowSource{queue_s, rays, shadow, 1, npix}, n_e};
-    PathSink sink{ExtendSinkFast{queue_e, hits, redo, redo_count}, ShadowSink{queue_s, shadow, 1, npix}, n_e};
+    if(blockIdx.x == 0 && threadIdx.x == 0 && n_s) atomicAdd(shadow_rays_stat, (unsigned long long)n_s);
+    PathSource src{ExtendSource{queue_e, rays, nullptr}, ShadowSource{queue_s, rays, shadow, 1, npix}, n_e};
+    PathSink sink{ExtendSinkFast{queue_e, hits, redo, redo_count}, ShadowApplySink{queue_s, shadow, thr, acc}, n_e};
     trace_ordered<QUANT>(sc, src, sink, next_counter, n_e + n_s, s_stack);
 }
 
@@ -230,9 +262,10 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel
 
 void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue_e, const unsigned *count_e,
                             const unsigned *queue_s, const unsigned *count_s, const PathRay *rays, PathHit *hits,
-                            ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo, unsigned *redo_count) {
+                            ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo, unsigned *redo_count,
+                            const PathThroughput *thr, PathAccum *acc, unsigned long long *shadow_rays_stat) {
     hipLaunchKernelGGL(sc.hdr.quantised ? path_trace_fast_kernel<true> : path_trace_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue_e, count_e, queue_s, count_s, rays,
-                       hits, shadow, npix, next_counter, redo, redo_count);
+                       hits, shadow, npix, next_counter, redo, redo_count, thr, acc, shadow_rays_stat);
 }
 
 void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n,
@@ -248,9 +281,9 @@ void launch_intersect_fast(hipStream_t s, const FastScene &sc, int blocks, const
 }
 
 void launch_extend(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
-                   const PathRay *rays, PathHit *hits, unsigned *next_counter) {
+                   const PathRay *rays, PathHit *hits, unsigned *next_counter, bool second_pass) {
     hipLaunchKernelGGL(extend_kernel, dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, queue, count, rays, hits,
-                       next_counter);
+                       next_counter, second_pass);
 }
 
 void launch_extend_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
