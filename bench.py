@@ -357,6 +357,16 @@ def main():
                     out["roofline"]["traffic"] = tot / max(n_launch, 1)
                     out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_file)
                     out["roofline"]["algorithmic_bytes_per_launch"] = out["roofline"]["rays_per_launch"] * b_ray
+                    # vector-ALU issue occupancy of the main kernel in the same profile: wave instructions x 4 cycles
+                    # over (cycles x 1024 SIMDs); GRBM_GUI_ACTIVE sums the 8 XCDs
+                    m = pmc[main[0]] if main else None
+                    if m and "SQ_INSTS_VALU" in m and "GRBM_GUI_ACTIVE" in m:
+                        cyc = m["GRBM_GUI_ACTIVE"]["total"] / 8.0
+                        out["roofline"]["valu_issue_busy"] = m["SQ_INSTS_VALU"]["total"] * 4.0 / (cyc * 1024.0)
+                    out["roofline"]["note"] = ("achieved = the REFERENCE algorithm's bytes per ray (48-byte nodes in its visiting order, "
+                                               "counted by the oracle) x rays / kernel time; traffic = bytes this kernel really moved. "
+                                               "A fraction above 1 means the kernel answers the same queries with fewer bytes than that "
+                                               "algorithm needs; what then limits it is vector-ALU issue (valu_issue_busy).")
             if prof:
                 out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "trace_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms")}
                 if "draws" in prof:
