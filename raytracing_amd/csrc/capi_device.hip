@@ -124,7 +124,7 @@ struct pt_pass {
     DeviceArray d_mesh_buf, d_scene_buf, d_spill, d_tex_table;  // the two traversal buffers (device_types.h)
     DeviceArray d_redo_isect;  // redo list of the ordered intersect
     int traversal_mode = 0;               // 0 ordered + exact fallback, 1 reference order only
-    int quantise = -1;                    // wide nodes: -1 by scene size, 0 WNodes, 1 QNodes
+    int quantise = -1;                    // wide nodes: 0 WNodes, 1 or -1 (default) QNodes
     int n_textures = 0;
     int spill_depth = 0;
     size_t n_material_floats = 0;
