@@ -181,8 +181,10 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 
 /* Traversal strategy; no counterpart in the reference.
  *   0 (default) ordered traversal (nearer child first, reciprocal-direction culling,
- *     batched leaves); rays whose two closest hits lie within 2e-4 of each other are traced
- *     again in the reference's order, so results are those of mode 1;
+ *     batched leaves); rays whose closest hit the reference's order-dependent pruning could
+ *     have dropped (a second hit at the same distance, or nearer than the boxes that lead
+ *     to the closest one) are traced again in the reference's order, so results are those
+ *     of mode 1;
  *   1 the reference's visiting order for every ray (shader/pathtracing.glsl:254-316). */
 int pt_pass_set_traversal(pt_pass *pass, int mode);
 

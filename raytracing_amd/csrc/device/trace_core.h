@@ -146,7 +146,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                     wdx = d[0]; wdy = d[1]; wdz = d[2];
                     best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
                     // A ray the ordered traversal could not decide comes with that pass's closest
-                    // distance.  What the reference returns lies within 2e-4 of it, and a subtree
+                    // distance.  What the reference returns lies within 5e-4 of it, and a subtree
                     // whose box is entered beyond 1.001 times that distance can neither hold the
                     // answer nor prune a subtree that does (its hits are farther than every such
                     // subtree's entry), so it is skipped: start from that bound instead of infinity.

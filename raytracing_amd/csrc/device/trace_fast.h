@@ -22,9 +22,11 @@
 //       margin to spare;
 //   (3) subtrees are pruned only beyond t_best * (1 + 1e-3) (+ an absolute term scaled by
 //       the scene size), so every hit inside the near-tie band is seen;
-//   (4) the smallest t among all OTHER hits is tracked, and a ray whose runner-up lies
-//       within 2e-4 of the winner is reported as ambiguous: the caller re-traces it with
-//       the reference-order kernel (trace_core.h), which is exact by construction.
+//   (4) the smallest t among all OTHER hits is tracked, and a ray whose runner-up ties with
+//       the winner or lies below the entry distance of the winner's parent box or scene leaf
+//       box (the only results that could have pruned the winner away) is reported as
+//       ambiguous: the caller re-traces it with the reference-order kernel (trace_core.h),
+//       which is exact by construction.
 // The triangle test itself is the reference's Moller-Trumbore, bit for bit.
 // Occlusion queries ("is there any candidate hit") have no order dependence at all.
 // (The host refuses this kernel for buffers whose child boxes are not inside their parents'.)
@@ -126,6 +128,8 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
     LaneHit best;
     best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
     float second_t = RT_INF, abs_slack = 0.0f;
+    float inst_tw = 0.0f;   // entry distance of the current instance's scene leaf box
+    float best_gate = 0.0f; // for the closest hit: the larger entry distance of its parent box and its scene leaf box
     int cur_inst = -1;
     unsigned ref = 0;
     float tn = 0;
@@ -189,7 +193,15 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                     tn = __uint_as_float(e.y);
                     have = !(tn > prune_t);
                 } else {
-                    const bool ambiguous = !any_hit && best.tri >= 0 && second_t <= best.t * 1.0002f + 2.0f * abs_slack;
+                    // The reference loses the closest candidate only by pruning a box above it,
+                    // which needs a result closer than that box's entry distance: the runner-up
+                    // below best_gate (relaxed by the error of the reciprocal arithmetic), or an
+                    // exact tie (then the visiting order decides).  A gate well beyond the hit
+                    // itself means box and triangle arithmetic disagree: nothing is assumed then,
+                    // and the second pass starts without a bound.
+                    const bool odd = best_gate > best.t * 1.0005f + 4.0f * abs_slack;
+                    const bool ambiguous = !any_hit && best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f);
+                    if(ambiguous && odd) best.t = RT_INF;
                     sink.store(ray_idx, best, ambiguous);
                     active = false;
                 }
@@ -334,6 +346,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                     cdz = (q2.x * wdx + q2.y * wdy) + q2.z * wdz;
                     cix = fast_rcp(cdx); ciy = fast_rcp(cdy); ciz = fast_rcp(cdz);
                     in_mesh = true;
+                    inst_tw = tw;
                     cur_inst = (int)((idx - sc.hdr.inst_base) >> 1);
                     ref = __float_as_uint(q3.z);  // wide mesh root; its own box is implied by the boxes below it
                 }
@@ -366,6 +379,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                             best.t = t; best.u = u; best.v = v;
                             best.tri = __float_as_int(q3.w);  // TLeaf::triangle
                             best.inst = cur_inst;
+                            best_gate = fmaxf(t0, inst_tw);
                             if(any_hit) sp = 0;
                         }
                     } else {
