@@ -341,6 +341,12 @@ def main():
                                    "avg_launch_ms": ms / launches, "launches": int(launches),
                                    "algorithmic_bytes_per_ray": b_ray,
                                    "rays_per_launch": rays_in_kernel / launches}
+                if wl != "casa_isect" and world == 1:
+                    # The same product over the WHOLE timed region (shading and everything else included,
+                    # draws overlapping as they do in use): a lower bound of what the traversal kernels
+                    # sustain then; `achieved` above is per launch with one draw in flight, as events can time it.
+                    whole = total_rays * b_ray / dt / 1e9
+                    out["roofline"]["whole_step_with_draws_in_flight"] = {"achieved": whole, "frac": whole / HBM_PEAK_GBS}
             # HBM bytes per launch of the same kernels, from the committed rocprofv3 --pmc passes
             # (FETCH_SIZE + WRITE_SIZE; bench.py cannot collect counters on itself)
             pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % wl)

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
         const V3 position = ray_o + hit_t * ray_d;
         const int materialPtr = ia.material_ptr;
 
+        cx.bind_material(materialPtr, uvx, uvy);
         if(dep == 0) {
             // first-hit outputs, :640-655 and :682-688
             BSDFQueryRecord ab;

@@ -159,15 +159,23 @@ struct ShadeCtx {
     float sky_light_sum;
     Sampler rng;
 
-    __device__ float mat(int i) const { return materials[i]; }
+    // The material record of the vertex being shaded, read once (bind_material): every
+    // query of a vertex names the same record and the same uv, and the reference's per-call
+    // texture fetch + pow (RoughConductor.glsl:3-32) is a pure function of them.
+    float m_type = 0.0f, m_alpha = 0.0f, m_metallic = 0.0f, m_eta = 0.0f;
+    V3 m_albedo;
 
-    __device__ V3 base_albedo(const BSDFQueryRecord &b) const {
-        V3 albedo = v3(mat(b.mptr + 1), mat(b.mptr + 2), mat(b.mptr + 3));
-        int albedo_map = roundint(mat(b.mptr + 6));
-        if(albedo_map >= 0 && albedo_map < n_textures)
-            albedo = powv(texture_rgb(textures[albedo_map], b.uvx, b.uvy), 2.2f);
-        return albedo;
+    __device__ void bind_material(int mptr, float uvx, float uvy) {
+        m_type = materials[mptr];
+        m_albedo = v3(materials[mptr + 1], materials[mptr + 2], materials[mptr + 3]);
+        m_alpha = materials[mptr + 4];
+        m_metallic = materials[mptr + 5];
+        const int albedo_map = roundint(materials[mptr + 6]);
+        m_eta = roundint(m_type) == 2 ? materials[mptr + 7] : 0.0f;  // (conductor records end after 7 floats)
+        if(albedo_map >= 0 && albedo_map < n_textures) m_albedo = powv(texture_rgb(textures[albedo_map], uvx, uvy), 2.2f);
     }
+    __device__ float mat(int i) const { return i == 0 ? m_type : i == 4 ? m_alpha : i == 5 ? m_metallic : m_eta; }
+    __device__ V3 base_albedo(const BSDFQueryRecord &) const { return m_albedo; }
 
     // S/materials/materials.glsl:5-31
     __device__ V3 sample_GGX(float alpha, float &pdf) {
@@ -206,8 +214,8 @@ struct ShadeCtx {
     __device__ V3 eval_RoughConductor(const BSDFQueryRecord &b) const {
         if(signf(b.wi.z) != signf(b.wo.z)) return v3(0.0f);
         V3 albedo = base_albedo(b);
-        float alpha = mat(b.mptr + 4);
-        float metallic = mat(b.mptr + 5);
+        float alpha = mat(4);
+        float metallic = mat(5);
         V3 F0 = mixv(v3(0.04f), albedo, metallic);
         V3 H = normalize(b.wi + b.wo);
         H = H * signf(H.z);
@@ -224,7 +232,7 @@ struct ShadeCtx {
     }
     __device__ float pdf_RoughConductor(const BSDFQueryRecord &b) const {
         if(signf(b.wi.z) != signf(b.wo.z)) return 0.0f;
-        float alpha = mat(b.mptr + 4);
+        float alpha = mat(4);
         V3 H = normalize(b.wi + b.wo);
         H = H * signf(H.z);
         float OdotH = fabsf(dot(b.wo, H));
@@ -232,7 +240,7 @@ struct ShadeCtx {
         return pdf / (4.0f * OdotH);
     }
     __device__ V3 sample_RoughConductor(BSDFQueryRecord &b, float &pdf) {
-        float alpha = mat(b.mptr + 4);
+        float alpha = mat(4);
         V3 H = sample_GGX(alpha, pdf);
         b.wo = reflect(-b.wi, H);
         b.eta = 1.0f;
@@ -248,8 +256,8 @@ struct ShadeCtx {
     // S/materials/RoughDielectric.glsl:7-133
     __device__ V3 eval_RoughDielectric(const BSDFQueryRecord &b) const {
         V3 albedo = base_albedo(b);
-        float alpha = mat(b.mptr + 4);
-        float eta = mat(b.mptr + 7);
+        float alpha = mat(4);
+        float eta = mat(7);
         if(b.wi.z < 0.0f) eta = 1.0f / eta;
         bool isreflect = signf(b.wi.z) == signf(b.wo.z);
         V3 H;
@@ -270,8 +278,8 @@ struct ShadeCtx {
         }
     }
     __device__ float pdf_RoughDielectric(const BSDFQueryRecord &b) const {
-        float alpha = mat(b.mptr + 4);
-        float eta = mat(b.mptr + 7);
+        float alpha = mat(4);
+        float eta = mat(7);
         if(b.wi.z < 0.0f) eta = 1.0f / eta;
         bool isreflect = signf(b.wi.z) == signf(b.wo.z);
         V3 H;
@@ -292,8 +300,8 @@ struct ShadeCtx {
     }
     __device__ V3 sample_RoughDielectric(BSDFQueryRecord &b, float &pdf) {
         V3 albedo = base_albedo(b);
-        float alpha = mat(b.mptr + 4);
-        float eta = mat(b.mptr + 7);
+        float alpha = mat(4);
+        float eta = mat(7);
         if(b.wi.z < 0.0f) eta = 1.0f / eta;
         pdf = -1.0f;
         float pdfH;
@@ -324,26 +332,26 @@ struct ShadeCtx {
 
     // S/materials/materials.glsl:82-111
     __device__ V3 eval_material(const BSDFQueryRecord &b) const {
-        int type = roundint(mat(b.mptr));
+        int type = roundint(mat(0));
         if(type == 1) return eval_RoughConductor(b);
         else if(type == 2) return eval_RoughDielectric(b);
         return v3(0.0f);
     }
     __device__ float pdf_material(const BSDFQueryRecord &b) const {
-        int type = roundint(mat(b.mptr));
+        int type = roundint(mat(0));
         if(type == 1) return pdf_RoughConductor(b);
         else if(type == 2) return pdf_RoughDielectric(b);
         return 0.0f;
     }
     __device__ V3 sample_material(BSDFQueryRecord &b, float &pdf) {
-        int type = roundint(mat(b.mptr));
+        int type = roundint(mat(0));
         if(type == 1) return sample_RoughConductor(b, pdf);
         else if(type == 2) return sample_RoughDielectric(b, pdf);
         pdf = -1.0f;
         return v3(0.0f);
     }
     __device__ V3 albedo_material(const BSDFQueryRecord &b) const {
-        int type = roundint(mat(b.mptr));
+        int type = roundint(mat(0));
         if(type == 1 || type == 2) return base_albedo(b);
         return v3(0.0f);
     }
