@@ -103,7 +103,13 @@ __device__ __forceinline__ int wrap_texel(float f, int n) {
 __device__ __forceinline__ V3 fetch_texel_rgb(const TexDesc &tx, int x, int y) {
     size_t base = ((size_t)y * tx.width + x) * tx.channels;
     float c[3] = {0.0f, 0.0f, 0.0f};
-    if(tx.format == 0) {
+    if(tx.format == 0 && tx.channels == 4) {
+        // RGBA8: the texel is one aligned word
+        const unsigned w = static_cast<const unsigned *>(tx.data)[(size_t)y * tx.width + x];
+        c[0] = (float)(w & 0xFFu) / 255.0f;
+        c[1] = (float)((w >> 8) & 0xFFu) / 255.0f;
+        c[2] = (float)((w >> 16) & 0xFFu) / 255.0f;
+    } else if(tx.format == 0) {
         const unsigned char *p = static_cast<const unsigned char *>(tx.data) + base;
         for(int k = 0; k < 3; k++)
             if(k < tx.channels) c[k] = (float)p[k] / 255.0f;
