@@ -220,23 +220,27 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
         if(dep >= P.MAX_DEPTH && dep != 0) continue;  // loop bound of :501 (the first hit's outputs are due even at MAX_DEPTH 0)
 
         // ---- geometry of the hit (what intersect_triangle / intersect_meshBVH return, :239-248, :275-276)
-        const InstAccel &ia = dp.inst[hit_inst];
+        // first 64 bytes of the instance record: rows of world-to-local, then root, material pointer
+        const float4 *ip = reinterpret_cast<const float4 *>(dp.inst + hit_inst);
+        const float4 ir0 = ip[0], ir1 = ip[1], ir2 = ip[2], ir3 = ip[3];
         V3 normal = g_normal;
         float uvx = g_uvx, uvy = g_uvy;
         if(!raster0) {
-            const float *tr = reinterpret_cast<const float *>(dp.tris + hit_tri);
+            // floats 8..23 of the 96-byte record (16-byte aligned): normals 9..17, uvs 18..23
+            const float4 *tr = reinterpret_cast<const float4 *>(dp.tris + hit_tri);
+            const float4 ta = tr[2], tb = tr[3], tc = tr[4], td = tr[5];
             const float wgt = 1.0f - hit_u - hit_v;
-            const V3 n0 = v3(tr[9], tr[10], tr[11]), n1 = v3(tr[12], tr[13], tr[14]), n2 = v3(tr[15], tr[16], tr[17]);
+            const V3 n0 = v3(ta.y, ta.z, ta.w), n1 = v3(tb.x, tb.y, tb.z), n2 = v3(tb.w, tc.x, tc.y);
             const V3 nloc = normalize(n0 * wgt + n1 * hit_u + n2 * hit_v);
-            uvx = tr[18] * wgt + tr[20] * hit_u + tr[22] * hit_v;
-            uvy = tr[19] * wgt + tr[21] * hit_u + tr[23] * hit_v;
-            const V3 nn = v3(nloc.x * ia.row[0][0] + nloc.y * ia.row[1][0] + nloc.z * ia.row[2][0],
-                             nloc.x * ia.row[0][1] + nloc.y * ia.row[1][1] + nloc.z * ia.row[2][1],
-                             nloc.x * ia.row[0][2] + nloc.y * ia.row[1][2] + nloc.z * ia.row[2][2]);
+            uvx = tc.z * wgt + td.x * hit_u + td.z * hit_v;
+            uvy = tc.w * wgt + td.y * hit_u + td.w * hit_v;
+            const V3 nn = v3(nloc.x * ir0.x + nloc.y * ir1.x + nloc.z * ir2.x,
+                             nloc.x * ir0.y + nloc.y * ir1.y + nloc.z * ir2.y,
+                             nloc.x * ir0.z + nloc.y * ir1.z + nloc.z * ir2.z);
             normal = normalize(nn);
         }
         const V3 position = ray_o + hit_t * ray_d;
-        const int materialPtr = ia.material_ptr;
+        const int materialPtr = __float_as_int(ir3.y);  // InstAccel::material_ptr
 
         cx.bind_material(materialPtr, uvx, uvy);
         if(dep == 0) {
