@@ -350,7 +350,11 @@ def main():
             # HBM bytes per launch of the same kernels, from the committed rocprofv3 --pmc passes
             # (FETCH_SIZE + WRITE_SIZE; bench.py cannot collect counters on itself)
             pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % wl)
-            if "roofline" in out and os.path.exists(pmc_file):
+            # (the committed passes are of the default configuration of each workload)
+            default_cfg = args.depth == 8 and args.width is None and args.height is None and \
+                (wl != "synth_pt" or (args.tris == 10_000_000 and args.dielectric == 0.0 and args.textures == 0)) and \
+                (wl != "casa_isect" or args.rays == 1 << 24)
+            if "roofline" in out and os.path.exists(pmc_file) and default_cfg:
                 pmc = json.load(open(pmc_file))
                 names = ["intersect_fast_kernel", "intersect_kernel"] if wl == "casa_isect" else \
                         ["path_trace_fast_kernel", "extend_fast_kernel", "extend_kernel", "shadow_fast_kernel", "shadow_kernel"]
