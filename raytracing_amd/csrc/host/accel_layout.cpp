@@ -3,6 +3,11 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
 
 namespace rta {
 namespace {
@@ -38,11 +43,6 @@ float half_area(const BVHNodeInfo &n) {
     return x * y + y * z + z * x;
 }
 
-// Collapses binary trees (child index > parent index) into four-wide nodes.  A node takes its
-// two children and then, while it has room, replaces the inner child of largest surface by
-// that child's two children.  is_leaf(i) tells leaves; leaf_ref(i) / the returned slot numbers
-// make the references; a leaf child carries its reference parent's box when
-// leaf_box_of_parent, else its own.  Wide node k gets slot slot_base + 2 k.
 // Child boxes of one wide node on the node's 256-step grid, rounded outwards as decoded:
 // fmaf(step, scale, origin) <= lo and >= hi in fp32, scale = 2^(e - 127).
 void quantise_node(const uint32_t refs[4], const BVHNodeInfo *const boxes[4], QNode &q) {
@@ -94,28 +94,37 @@ void quantise_node(const uint32_t refs[4], const BVHNodeInfo *const boxes[4], QN
     }
 }
 
+// references of a wide record, whichever format
+inline uint32_t *wide_refs(TNode *rec, bool quantised) {
+    return quantised ? reinterpret_cast<QNode *>(rec)->c : reinterpret_cast<WNode *>(rec)->c;
+}
+
+// The wide nodes of the trees under `roots` (one group: the roots may share subtrees), numbered
+// from 0 within the group; a reference to an inner child holds that number until merge time.
+struct WideGroup {
+    std::vector<TNode> recs;      // stride slots per wide node
+    std::vector<int32_t> owner;   // reference node of wide node k
+    std::vector<uint8_t> height;  // height of the wide subtree under wide node k
+    bool ordered = true;          // every inner child has a larger number than its parent
+};
+
 template <class IsLeaf, class LeafRef>
-void build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::vector<int32_t> &roots, IsLeaf is_leaf,
-                      LeafRef leaf_ref, bool leaf_box_of_parent, uint32_t inner_kind, uint32_t slot_base, bool quantised,
-                      std::vector<TNode> &out, std::vector<uint32_t> &wide_of, std::vector<uint8_t> &wide_height) {
+void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *roots, size_t n_roots, IsLeaf is_leaf,
+                      LeafRef leaf_ref, bool leaf_box_of_parent, uint32_t inner_kind, bool quantised,
+                      std::vector<uint32_t> &wide_of, WideGroup &g) {
     const uint32_t stride = quantised ? 1u : 2u;  // slots per wide node
-    wide_of.assign(n_nodes, REF_NONE);
-    out.clear();
-    struct Kids { int32_t k[4]; };
-    std::vector<Kids> kids;  // inner children (reference node indices) of each wide node, -1 = none
-    std::vector<int32_t> work, owner;  // owner[k] = reference node of wide node k
-    auto wide_slot = [&](int32_t node) {
+    std::vector<int32_t> work;
+    auto wide_index = [&](int32_t node) {  // number of the node's wide node within the group (created on first use)
         if(wide_of[node] == REF_NONE) {
-            wide_of[node] = slot_base + (uint32_t)out.size();
-            out.resize(out.size() + stride);
-            kids.push_back(Kids{{-1, -1, -1, -1}});
-            owner.push_back(node);
+            wide_of[node] = (uint32_t)g.owner.size();
+            g.recs.resize(g.recs.size() + stride);
+            g.owner.push_back(node);
             work.push_back(node);
         }
         return wide_of[node];
     };
-    for(int32_t r : roots)
-        if(r >= 0 && (size_t)r < n_nodes && !is_leaf(r)) wide_slot(r);
+    for(size_t r = 0; r < n_roots; r++)
+        if(roots[r] >= 0 && (size_t)roots[r] < n_nodes && !is_leaf(roots[r])) wide_index(roots[r]);
     while(!work.empty()) {
         const int32_t n = work.back();
         work.pop_back();
@@ -141,7 +150,7 @@ void build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::vecto
             items[best + 1] = {nodes[c].rsIndex, c};
             cnt++;
         }
-        const size_t k = (wide_of[n] - slot_base) / stride;
+        const size_t k = wide_of[n];
         uint32_t refs[4];
         const BVHNodeInfo *boxes[4];
         for(int i = 0; i < 4; i++) {
@@ -153,15 +162,16 @@ void build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::vecto
                 refs[i] = leaf_ref(c);
                 boxes[i] = &nodes[leaf_box_of_parent ? items[i].parent : c];
             } else {
-                refs[i] = make_ref(inner_kind, wide_slot(c));  // (may grow `out`: it is indexed again below)
+                const uint32_t ck = wide_index(c);  // (may grow g.recs: indexed again below)
+                if(ck <= k) g.ordered = false;
+                refs[i] = make_ref(inner_kind, ck);
                 boxes[i] = &nodes[c];
-                kids[k].k[i] = c;
             }
         }
         if(quantised) {
-            quantise_node(refs, boxes, *reinterpret_cast<QNode *>(&out[k]));
+            quantise_node(refs, boxes, *reinterpret_cast<QNode *>(&g.recs[k]));
         } else {
-            WNode &w = *reinterpret_cast<WNode *>(&out[2 * k]);
+            WNode &w = *reinterpret_cast<WNode *>(&g.recs[2 * k]);
             memset(&w, 0, sizeof w);
             float *lo[4] = {w.lo0, w.lo1, w.lo2, w.lo3}, *hi[4] = {w.hi0, w.hi1, w.hi2, w.hi3};
             for(int i = 0; i < 4; i++) {
@@ -173,17 +183,90 @@ void build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::vecto
             }
         }
     }
-    // heights, children before parents (a child's reference index is larger than its parent's)
-    wide_height.assign(owner.size(), 1);
-    std::vector<uint32_t> order(owner.size());
-    for(size_t k = 0; k < owner.size(); k++) order[k] = (uint32_t)k;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return owner[a] > owner[b]; });
-    for(uint32_t k : order) {
+    // heights, children before parents: in creation order a child comes after its parent unless
+    // subtrees are shared; then order by the reference index (a child's is larger than its parent's)
+    const size_t n_wide = g.owner.size();
+    g.height.assign(n_wide, 1);
+    std::vector<uint32_t> order;
+    if(!g.ordered) {
+        order.resize(n_wide);
+        for(size_t k = 0; k < n_wide; k++) order[k] = (uint32_t)k;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g.owner[x] < g.owner[y]; });
+    }
+    for(size_t j = n_wide; j-- > 0;) {
+        const size_t k = g.ordered ? j : order[j];
+        const uint32_t *c = wide_refs(&g.recs[k * stride], quantised);
         int h = 1;
         for(int i = 0; i < 4; i++)
-            if(kids[k].k[i] >= 0) h = std::max<int>(h, 1 + wide_height[(wide_of[kids[k].k[i]] - slot_base) / stride]);
-        wide_height[k] = (uint8_t)std::min(h, 255);
+            if(c[i] != REF_NONE && (c[i] >> 30) == inner_kind) h = std::max<int>(h, 1 + g.height[c[i] & REF_INDEX_MASK]);
+        g.height[k] = (uint8_t)std::min(h, 255);
     }
+}
+
+// Runs fn(0) .. fn(n - 1) on up to `threads` threads, items handed out one at a time.
+template <class Fn>
+void parallel_items(size_t n, unsigned threads, Fn fn) {
+    if(threads <= 1 || n <= 1) {
+        for(size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    auto body = [&]() {
+        for(size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+    };
+    for(unsigned t = 1; t < threads && t < n; t++) pool.emplace_back(body);
+    body();
+    for(std::thread &t : pool) t.join();
+}
+
+unsigned layout_threads() {
+    const unsigned hc = std::thread::hardware_concurrency();
+    return hc == 0 ? 1u : (hc > 16u ? 16u : hc);
+}
+
+// Collapses binary trees (child index > parent index) into four-wide nodes.  A node takes its
+// two children and then, while it has room, replaces the inner child of largest surface by
+// that child's two children.  is_leaf(i) tells leaves; leaf_ref(i) makes their references; a
+// leaf child carries its reference parent's box when leaf_box_of_parent, else its own.  Wide
+// nodes are appended to `slots` from slot_base on (which is returned past them).  Trees that
+// share nothing (`disjoint`) are built side by side on several threads.
+template <class IsLeaf, class LeafRef>
+uint32_t build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::vector<int32_t> &roots, bool disjoint,
+                          IsLeaf is_leaf, LeafRef leaf_ref, bool leaf_box_of_parent, uint32_t inner_kind, uint32_t slot_base,
+                          bool quantised, std::vector<TNode> &slots, std::vector<uint32_t> &wide_of,
+                          std::vector<uint8_t> &wide_height) {
+    const uint32_t stride = quantised ? 1u : 2u;
+    wide_of.assign(n_nodes, REF_NONE);
+    std::vector<WideGroup> groups(disjoint ? roots.size() : 1);
+    if(disjoint)
+        parallel_items(roots.size(), layout_threads(), [&](size_t r) {
+            build_wide_group(nodes, n_nodes, &roots[r], 1, is_leaf, leaf_ref, leaf_box_of_parent, inner_kind, quantised, wide_of, groups[r]);
+        });
+    else
+        build_wide_group(nodes, n_nodes, roots.data(), roots.size(), is_leaf, leaf_ref, leaf_box_of_parent, inner_kind, quantised,
+                         wide_of, groups[0]);
+    // merge: group g's wide node k becomes slot slot_base + stride * (first[g] + k)
+    std::vector<size_t> first(groups.size() + 1, 0);
+    for(size_t g = 0; g < groups.size(); g++) first[g + 1] = first[g] + groups[g].owner.size();
+    const size_t n_wide = first.back();
+    if((uint64_t)slot_base + (uint64_t)stride * n_wide >= REF_INDEX_MASK) return REF_NONE;
+    slots.resize((size_t)slot_base + stride * n_wide);
+    wide_height.resize(n_wide);
+    parallel_items(groups.size(), layout_threads(), [&](size_t gi) {
+        WideGroup &g = groups[gi];
+        const uint32_t base = slot_base + stride * (uint32_t)first[gi];
+        for(size_t k = 0; k < g.owner.size(); k++) {
+            uint32_t *c = wide_refs(&g.recs[k * stride], quantised);
+            for(int i = 0; i < 4; i++)
+                if(c[i] != REF_NONE && (c[i] >> 30) == inner_kind) c[i] = make_ref(inner_kind, base + stride * (c[i] & REF_INDEX_MASK));
+            wide_of[g.owner[k]] = base + stride * (uint32_t)k;
+            wide_height[first[gi] + k] = g.height[k];
+        }
+        if(!g.recs.empty()) memcpy(&slots[base], g.recs.data(), g.recs.size() * sizeof(TNode));
+        std::vector<TNode>().swap(g.recs);
+    });
+    return slot_base + stride * (uint32_t)n_wide;
 }
 
 }  // namespace
@@ -200,8 +283,19 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
     }
     out.n_tris = n_tris;
     out.nested = true;
+    const bool timing = getenv("RTA_LAYOUT_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if(!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[layout] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
+    // ---- validation; heights (children come after their parents, so backwards)
     std::vector<uint8_t> has_parent(n_mesh_nodes, 0);
-    for(size_t i = 0; i < n_mesh_nodes; i++) {
+    bool shared = false;  // some node has two parents: the arrays form a DAG, not a forest
+    out.height.assign(n_mesh_nodes, 1);
+    for(size_t i = n_mesh_nodes; i-- > 0;) {
         if(mesh[i].triangleIndex >= 0) {
             if((size_t)mesh[i].triangleIndex >= n_tris) {
                 err = "mesh BVH node " + std::to_string(i) + " references a triangle out of range";
@@ -209,10 +303,14 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
             }
         } else {
             if(!check_children(mesh, n_mesh_nodes, i, "mesh", err)) return false;
-            has_parent[mesh[i].lsIndex] = 1;
-            has_parent[mesh[i].rsIndex] = 1;
+            const int32_t ls = mesh[i].lsIndex, rs = mesh[i].rsIndex;
+            if(has_parent[ls] || has_parent[rs] || ls == rs) shared = true;
+            has_parent[ls] = 1;
+            has_parent[rs] = 1;
+            out.height[i] = (uint8_t)std::min(std::max<int>(out.height[ls], out.height[rs]) + 1, 255);
         }
     }
+    lap("validate");
     // Slots: every reference node gets one 64-byte slot, inner nodes a TNode, leaves a TLeaf, in
     // depth-first order of each tree (node, subtree of ls, subtree of rs): a walk down a tree
     // moves through a shrinking address range, and a node often shares its 128-byte line with the
@@ -220,15 +318,17 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
     std::vector<uint32_t> &slot_of = out.slot_of;
     slot_of.assign(n_mesh_nodes, 0xFFFFFFFFu);
     uint32_t next = 0;
+    std::vector<int32_t> roots;
     {
         std::vector<int32_t> stack;
         for(size_t r = 0; r < n_mesh_nodes; r++) {
             if(has_parent[r]) continue;
+            roots.push_back((int32_t)r);
             stack.push_back((int32_t)r);
             while(!stack.empty()) {
                 const int32_t n = stack.back();
                 stack.pop_back();
-                if(slot_of[n] != 0xFFFFFFFFu) continue;  // reached twice: the arrays form a DAG, keep the first slot
+                if(slot_of[n] != 0xFFFFFFFFu) continue;  // reached twice: keep the first slot
                 slot_of[n] = next++;
                 if(mesh[n].triangleIndex < 0) {
                     stack.push_back(mesh[n].rsIndex);
@@ -237,10 +337,25 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
             }
         }
     }
+    lap("depth-first slots");
+    // ---- the same trees, four-wide, for the ordered traversal (sizes the buffer: first)
+    const bool disjoint = !shared && extra_roots.empty();
+    roots.insert(roots.end(), extra_roots.begin(), extra_roots.end());
+    out.quantised = quantise != 0;
+    out.wide_stride = out.quantised ? 1u : 2u;
+    out.wide_base = (next + 1u) & ~1u;
+    out.slots.clear();
+    const uint32_t end = build_wide_nodes(
+        mesh, n_mesh_nodes, roots, disjoint, [&](int32_t c) { return mesh[c].triangleIndex >= 0; },
+        [&](int32_t c) { return make_ref(REF_TRIANGLE, slot_of[c]); }, true, REF_MESH_INNER, out.wide_base, out.quantised, out.slots,
+        out.wide_of, out.wide_height);
+    if(end == REF_NONE) {
+        err = "scene too large for 30-bit references";
+        return false;
+    }
+    lap("wide nodes");
+    // ---- binary nodes and leaves
     auto mesh_ref = [&](int32_t c) { return make_ref(mesh[c].triangleIndex >= 0 ? REF_TRIANGLE : REF_MESH_INNER, slot_of[c]); };
-    out.slots.assign(next, TNode());
-    memset(out.slots.data(), 0, out.slots.size() * sizeof(TNode));
-    out.height.assign(n_mesh_nodes, 1);
     const float inf = std::numeric_limits<float>::infinity();
     auto fill_leaf = [&](int32_t node, const float *plo, const float *phi) {
         TLeaf &l = *reinterpret_cast<TLeaf *>(&out.slots[slot_of[node]]);
@@ -254,44 +369,32 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
         }
         l.triangle = (uint32_t)mesh[node].triangleIndex;
     };
-    for(size_t ii = n_mesh_nodes; ii-- > 0;) {
-        const BVHNodeInfo &p = mesh[ii];
-        if(p.triangleIndex >= 0) {
-            if(!has_parent[ii]) fill_leaf((int32_t)ii, nullptr, nullptr);  // a one-triangle mesh
-            continue;
+    // (every node writes its own slot and the slots of its leaf children: ranges of nodes are
+    // independent unless subtrees are shared)
+    const size_t n_chunks = shared ? 1 : std::min<size_t>(256, (n_mesh_nodes + 65535) / 65536);
+    std::vector<uint8_t> chunk_nested(n_chunks, 1);
+    parallel_items(n_chunks, layout_threads(), [&](size_t ch) {
+        const size_t lo = n_mesh_nodes * ch / n_chunks, hi = n_mesh_nodes * (ch + 1) / n_chunks;
+        for(size_t ii = hi; ii-- > lo;) {
+            const BVHNodeInfo &p = mesh[ii];
+            if(p.triangleIndex >= 0) {
+                if(!has_parent[ii]) fill_leaf((int32_t)ii, nullptr, nullptr);  // a one-triangle mesh
+                continue;
+            }
+            if(!box_inside(mesh[p.lsIndex], p) || !box_inside(mesh[p.rsIndex], p)) chunk_nested[ch] = 0;
+            TNode &t = out.slots[slot_of[ii]];
+            set_box(t.lo0, t.hi0, mesh[p.lsIndex]);
+            set_box(t.lo1, t.hi1, mesh[p.rsIndex]);
+            t.c0 = mesh_ref(p.lsIndex);
+            t.c1 = mesh_ref(p.rsIndex);
+            // a leaf carries the exact box of its parent in the reference tree
+            for(int32_t c : {p.lsIndex, p.rsIndex})
+                if(mesh[c].triangleIndex >= 0) fill_leaf(c, p.aa, p.bb);
         }
-        if(!box_inside(mesh[p.lsIndex], p) || !box_inside(mesh[p.rsIndex], p)) out.nested = false;
-        TNode &t = out.slots[slot_of[ii]];
-        set_box(t.lo0, t.hi0, mesh[p.lsIndex]);
-        set_box(t.lo1, t.hi1, mesh[p.rsIndex]);
-        t.c0 = mesh_ref(p.lsIndex);
-        t.c1 = mesh_ref(p.rsIndex);
-        // a leaf carries the exact box of its parent in the reference tree
-        for(int32_t c : {p.lsIndex, p.rsIndex})
-            if(mesh[c].triangleIndex >= 0) fill_leaf(c, p.aa, p.bb);
-        const int h = std::max<int>(out.height[p.lsIndex], out.height[p.rsIndex]) + 1;
-        out.height[ii] = (uint8_t)std::min(h, 255);
-    }
-    // ---- the same trees, four-wide, for the ordered traversal
-    std::vector<int32_t> roots;
-    for(size_t r = 0; r < n_mesh_nodes; r++)
-        if(!has_parent[r]) roots.push_back((int32_t)r);
-    roots.insert(roots.end(), extra_roots.begin(), extra_roots.end());
-    out.quantised = quantise != 0;
-    out.wide_stride = out.quantised ? 1u : 2u;
-    out.wide_base = (next + 1u) & ~1u;
-    std::vector<TNode> wide;
-    build_wide_nodes(
-        mesh, n_mesh_nodes, roots, [&](int32_t c) { return mesh[c].triangleIndex >= 0; },
-        [&](int32_t c) { return make_ref(REF_TRIANGLE, slot_of[c]); }, true, REF_MESH_INNER, out.wide_base, out.quantised, wide,
-        out.wide_of, out.wide_height);
-    if((uint64_t)out.wide_base + (uint64_t)wide.size() >= REF_INDEX_MASK) {
-        err = "scene too large for 30-bit references";
-        return false;
-    }
-    out.slots.resize((size_t)out.wide_base + wide.size());
-    if(out.wide_base > next) memset(&out.slots[next], 0, sizeof(TNode));
-    if(!wide.empty()) memcpy(&out.slots[out.wide_base], wide.data(), wide.size() * sizeof(TNode));
+    });
+    for(uint8_t n : chunk_nested)
+        if(!n) out.nested = false;
+    lap("binary nodes and leaves");
     return true;
 }
 
@@ -403,10 +506,18 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
     // ---- the scene tree four-wide (an instance child keeps its own box: the scene leaf box)
     std::vector<uint32_t> swide_of;
     std::vector<uint8_t> swide_height;
-    build_wide_nodes(
-        scene, n_scene_nodes, std::vector<int32_t>{0}, [&](int32_t c) { return scene[c].instanceIndex >= 0; },
-        [&](int32_t c) { return scene_ref(c); }, false, REF_SCENE_INNER, inst_base + 2u * (uint32_t)n_inst, ml.quantised,
-        out.wide_nodes, swide_of, swide_height);
+    {
+        std::vector<TNode> all;  // sized by the builder: [0, first wide slot) stays unused here
+        const uint32_t wide_first = inst_base + 2u * (uint32_t)n_inst;
+        const uint32_t end = build_wide_nodes(
+            scene, n_scene_nodes, std::vector<int32_t>{0}, false, [&](int32_t c) { return scene[c].instanceIndex >= 0; },
+            [&](int32_t c) { return scene_ref(c); }, false, REF_SCENE_INNER, wide_first, ml.quantised, all, swide_of, swide_height);
+        if(end == REF_NONE) {
+            err = "scene too large for 30-bit references";
+            return false;
+        }
+        out.wide_nodes.assign(all.begin() + wide_first, all.end());
+    }
     out.header.quantised = ml.quantised ? 1u : 0u;
     out.header.wide_root_ref = scene[0].instanceIndex >= 0 ? out.header.root_ref : make_ref(REF_SCENE_INNER, swide_of[0]);
     // reference order: each level of a walk defers at most one sibling; ordered walk: three per wide level
