@@ -158,3 +158,64 @@ def test_degenerate_rays(casa, oracle_mod, gpu_ctx):
         assert nan_rows.sum() >= 500 and (got3["triangle"][nan_rows] == -1).all()
     p.destroy()
     sb.release()
+
+
+def _soup(rng, n, scale=1.0, offset=(0, 0, 0)):
+    t = np.zeros((n, 24), np.float32)
+    c = rng.uniform(-1, 1, (n, 1, 3)) * scale
+    t[:, :9] = (c + rng.normal(0, 0.05 * scale, (n, 3, 3)) + np.asarray(offset, np.float32)).reshape(n, 9)
+    t[:, 9:18] = np.tile([0, 0, 1], 3)
+    return t
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_hostile_geometry(oracle_mod, gpu_ctx, fmt):
+    """Scales from 1e-6 to 1e6, a mesh 1e7 from the origin (an ulp there is 1), coplanar triangles,
+    every triangle twice (exact ties in t: the visiting order decides), rotated / non-uniformly
+    scaled / mirrored instances that overlap, a one- and a two-triangle mesh.  Rays are aimed at
+    the instances from nearby, so that most of them hit something."""
+    from raytracing_amd import device, scene
+    rng = np.random.default_rng(17)
+    b = scene.SceneBuilder()
+    meshes = [_soup(rng, 400, 1e-6), _soup(rng, 400, 1e6), _soup(rng, 300, 1.0, (1e7, -1e7, 3e6)), _soup(rng, 1), _soup(rng, 2)]
+    flat = _soup(rng, 200)
+    flat[:, 2:9:3] = 0.25
+    flat[100:] = flat[:100]
+    meshes.append(flat)
+    dup = _soup(rng, 300, 2.0)
+    meshes.append(np.concatenate([dup, dup]))
+    ids = [b.add_mesh(m) for m in meshes]
+    for i in ids:
+        b.add_instance(i)
+    b.add_instance(ids[6], scene.transform_matrix((0.5, 0.2, -0.3), (30, 45, 60), (1.0, 0.2, 3.0)))
+    b.add_instance(ids[6], scene.transform_matrix((-0.5, 0, 0), (0, 0, 0), (-1.0, 1.0, 1.0)))
+    b.add_instance(ids[0], scene.transform_matrix((3, 0, 0), (10, 20, 30), (1e3, 1e3, 1e3)))
+    sd = b.finish()
+    rays = []
+    for k in range(len(sd.instances)):
+        leaf = np.flatnonzero(sd.scene_nodes["inst"] == k)[0]
+        lo, hi = sd.scene_nodes["aa"][leaf][:3].astype(np.float64), sd.scene_nodes["bb"][leaf][:3].astype(np.float64)
+        ext = np.maximum(hi - lo, 1e-30)
+        n = 20000
+        target = lo + rng.uniform(0, 1, (n, 3)) * ext
+        origin = (lo + hi) / 2 + rng.normal(0, 1, (n, 3)) * ext * 1.5
+        d = target - origin
+        d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-300)
+        rays.append(np.concatenate([origin, d], 1))
+    rays = np.ascontiguousarray(np.concatenate(rays), np.float32)
+    sb = device.SceneBuffers(gpu_ctx, sd)
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    p.bind_scene(sb)
+    p.set_wide_nodes(fmt)
+    hits = device.trace_rays(p, rays)
+    ref, _ = oracle_mod.OracleScene(sd).intersect(rays)
+    assert (ref["triangle"] >= 0).mean() > 0.2
+    _check(hits, ref)
+    assert p.stats()["reference_order_forced"] == 0
+    # the doubled mesh: both copies of a triangle are hit at the same t, the reference's order picks one
+    dup_inst = ref["instance"] == 6
+    assert dup_inst.sum() > 1000 and len(np.unique(ref["triangle"][dup_inst] >= sd.tri_count[:6].sum() + 300)) == 2
+    p.set_traversal(1)
+    _check(device.trace_rays(p, rays), ref)
+    p.destroy()
+    sb.release()
