@@ -1054,10 +1054,11 @@ int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
             launch_intersect_fast(s, make_fast_scene(p), (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n,
                                   static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT, redo, cnt + CNT_INTERSECT + 1);
             launch_intersect(s, sc, p->redo_blocks, static_cast<const float *>(rays->dptr), (unsigned)n, redo,
-                             cnt + CNT_INTERSECT + 1, static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT + 2);
+                             cnt + CNT_INTERSECT + 1, static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT + 2,
+                             static_cast<unsigned long long *>(p->d_stats.p) + 4);
         } else {
             launch_intersect(s, sc, (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n, nullptr, nullptr,
-                             static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT);
+                             static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT, nullptr);
         }
     }
     HIP_TRY(hipGetLastError());

@@ -58,7 +58,8 @@ struct FastScene;
 // closest hit for n rays given as 6 floats each; hits as pt_hit records.  With redo != nullptr
 // only the rays listed there (count read from *redo_count) are traced.
 void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n,
-                      const unsigned *redo, const unsigned *redo_count, pt_hit *hits, unsigned *next_counter);
+                      const unsigned *redo, const unsigned *redo_count, pt_hit *hits, unsigned *next_counter,
+                      unsigned long long *retraced_stat);
 // ordered form: undecided rays are appended to redo instead of being written
 void launch_intersect_fast(hipStream_t s, const FastScene &sc, int blocks, const float *rays, unsigned n,
                            pt_hit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count);

@@ -60,8 +60,10 @@ struct HitSinkFast {
 
 __global__ __launch_bounds__(TRACE_BLOCK) void intersect_kernel(TraceScene sc, const float *rays, unsigned n,
                                                                 const unsigned *redo, const unsigned *redo_count,
-                                                                pt_hit *hits, unsigned *next_counter) {
+                                                                pt_hit *hits, unsigned *next_counter,
+                                                                unsigned long long *retraced_stat) {
     __shared__ uint2 s_stack[LDS_STACK * TRACE_BLOCK];
+    if(redo && blockIdx.x == 0 && threadIdx.x == 0 && *redo_count) atomicAdd(retraced_stat, (unsigned long long)*redo_count);
     RaySource src{rays, redo, hits};
     HitSink sink{hits, redo};
     trace_persistent(sc, src, sink, next_counter, redo ? *redo_count : n, s_stack);
@@ -269,9 +271,10 @@ void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, cons
 }
 
 void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n,
-                      const unsigned *redo, const unsigned *redo_count, pt_hit *hits, unsigned *next_counter) {
+                      const unsigned *redo, const unsigned *redo_count, pt_hit *hits, unsigned *next_counter,
+                      unsigned long long *retraced_stat) {
     hipLaunchKernelGGL(intersect_kernel, dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, rays, n, redo, redo_count, hits,
-                       next_counter);
+                       next_counter, retraced_stat);
 }
 
 void launch_intersect_fast(hipStream_t s, const FastScene &sc, int blocks, const float *rays, unsigned n,
