@@ -159,3 +159,27 @@ def test_albedo_maps_with_one_three_and_four_channels(small_sky, oracle_mod, gpu
     assert cnt["ldr_tex_fetches"] > 0
     covered = out["instanceIndex"] >= 0
     assert all((out["instanceIndex"] == k).any() for k in range(3)) and covered.mean() > 0.05
+
+
+def test_render_of_hostile_geometry(small_sky, oracle_mod, gpu_ctx):
+    """The scene of extreme scales, doubled and coplanar triangles and mirrored instances, path
+    traced from two viewpoints (one inside the doubled mesh): every output word as the oracle's."""
+    from conftest import hostile_scene
+    from raytracing_amd import device, scene
+    sd = hostile_scene()
+    sb = device.SceneBuffers(gpu_ctx, sd, small_sky)
+    osc = oracle_mod.OracleScene(sd, small_sky)
+    p = device.PathTracingPass(gpu_ctx, 96, 54)
+    p.bind_scene(sb)
+    for v2w in (scene.transform_matrix((0.0, 1.0, 7.0), (-8.0, 0.0, 0.0), (1, 1, 1)),
+                scene.transform_matrix((0.2, 0.1, 0.3), (0.0, 100.0, 0.0), (1, 1, 1))):
+        prm = scene.make_params(96, 54, v2w, small_sky, spp=1, frame=3, jitter=(0.5, 0.5), max_depth=4)
+        p.set_params(prm)
+        p.draw()
+        ref, cnt = osc.render(prm, None)
+        out = p.download()
+        check(out, ref)
+        assert (out["instanceIndex"] >= 0).mean() > 0.1
+    assert p.stats()["rays_retraced"] > 0
+    p.destroy()
+    sb.release()
