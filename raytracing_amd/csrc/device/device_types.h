@@ -38,8 +38,8 @@ struct alignas(64) TNode {
 static_assert(sizeof(TNode) == 64, "traversal node is 64 bytes");
 
 // Four-wide node of the ordered traversal, 128 bytes, 128-byte aligned (an even slot): up to
-// four subtrees of the reference's binary tree, gathered by collapsing the node with the
-// children of its larger children.  The first half reads like a TNode with two more
+// four subtrees of the reference's binary tree, gathered by dissolving inner nodes below it
+// (which ones: planned on the host so that a ray visits as few wide nodes as possible).  The first half reads like a TNode with two more
 // references.  A child that is a triangle carries the box of its PARENT in the reference tree
 // (the reference tests no box of the leaf itself); an absent child is REF_NONE.
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;

@@ -108,11 +108,77 @@ struct WideGroup {
     bool ordered = true;          // every inner child has a larger number than its parent
 };
 
+// Which inner nodes stay (become wide nodes) and which dissolve into their parent's slots,
+// chosen to minimise the summed surface of the nodes that stay (the expected number of wide
+// nodes a ray visits), by dynamic programming over "subtree n may use up to i child slots of
+// the wide node above it" (i = 1..3; with one slot the node stays and spreads four slots over
+// its own two subtrees).  Leaves cost nothing here: a triangle child is tested against its
+// reference parent's box whatever happens above it.
+struct CollapsePlan {
+    std::vector<float> cost;   // [3 * n + (i - 1)]
+    std::vector<uint8_t> dec;  // bits 0-1: slots of ls when the node stays, minus 1; bit 2: with two slots, split 1+1;
+                               // bits 3-4: with three slots: 0 stay, 1 split 1+2, 2 split 2+1, 3 split 1+1; bit 7: done
+};
+
+template <class IsLeaf>
+void plan_collapse(const BVHNodeInfo *nodes, const int32_t *roots, size_t n_roots, size_t n_nodes, IsLeaf is_leaf, CollapsePlan &pl) {
+    std::vector<int32_t> stack;
+    auto C = [&](int32_t n, int i) { return is_leaf(n) ? 0.0f : pl.cost[3 * (size_t)n + (i - 1)]; };
+    for(size_t r = 0; r < n_roots; r++) {
+        if(roots[r] < 0 || (size_t)roots[r] >= n_nodes || is_leaf(roots[r])) continue;
+        stack.push_back(roots[r]);
+        while(!stack.empty()) {
+            const int32_t n = stack.back();
+            if(pl.dec[n] & 0x80u) {
+                stack.pop_back();
+                continue;
+            }
+            const int32_t ls = nodes[n].lsIndex, rs = nodes[n].rsIndex;
+            const bool ls_ready = is_leaf(ls) || (pl.dec[ls] & 0x80u), rs_ready = is_leaf(rs) || (pl.dec[rs] & 0x80u);
+            if(!ls_ready || !rs_ready) {
+                if(!rs_ready) stack.push_back(rs);
+                if(!ls_ready) stack.push_back(ls);
+                continue;
+            }
+            stack.pop_back();
+            // the node stays: four slots over its two subtrees
+            int j4 = 2;
+            float best = C(ls, 2) + C(rs, 2);
+            for(int j : {1, 3}) {
+                const float c = C(ls, j) + C(rs, 4 - j);
+                if(c < best) {
+                    best = c;
+                    j4 = j;
+                }
+            }
+            const float stay = half_area(nodes[n]) + best;
+            uint8_t d = (uint8_t)(j4 - 1);
+            float c2 = stay;
+            const float s11 = C(ls, 1) + C(rs, 1);
+            if(s11 < c2) {
+                c2 = s11;
+                d |= 4u;
+            }
+            float c3 = stay;
+            unsigned d3 = 0;
+            const float s12 = C(ls, 1) + C(rs, 2), s21 = C(ls, 2) + C(rs, 1);
+            if(s11 < c3) { c3 = s11; d3 = 3; }
+            if(s12 < c3) { c3 = s12; d3 = 1; }
+            if(s21 < c3) { c3 = s21; d3 = 2; }
+            pl.cost[3 * (size_t)n] = stay;
+            pl.cost[3 * (size_t)n + 1] = c2;
+            pl.cost[3 * (size_t)n + 2] = c3;
+            pl.dec[n] = (uint8_t)(d | (d3 << 3) | 0x80u);
+        }
+    }
+}
+
 template <class IsLeaf, class LeafRef>
 void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *roots, size_t n_roots, IsLeaf is_leaf,
                       LeafRef leaf_ref, bool leaf_box_of_parent, uint32_t inner_kind, bool quantised,
-                      std::vector<uint32_t> &wide_of, WideGroup &g) {
+                      std::vector<uint32_t> &wide_of, CollapsePlan &plan, WideGroup &g) {
     const uint32_t stride = quantised ? 1u : 2u;  // slots per wide node
+    plan_collapse(nodes, roots, n_roots, n_nodes, is_leaf, plan);
     std::vector<int32_t> work;
     auto wide_index = [&](int32_t node) {  // number of the node's wide node within the group (created on first use)
         if(wide_of[node] == REF_NONE) {
@@ -129,26 +195,35 @@ void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *r
         const int32_t n = work.back();
         work.pop_back();
         struct Item { int32_t node, parent; } items[4];
-        int cnt = 2;
-        items[0] = {nodes[n].lsIndex, n};
-        items[1] = {nodes[n].rsIndex, n};
-        while(cnt < 4) {
-            int best = -1;
-            float best_area = -1.0f;
-            for(int i = 0; i < cnt; i++)
-                if(!is_leaf(items[i].node)) {
-                    const float a = half_area(nodes[items[i].node]);
-                    if(a > best_area || best < 0) {
-                        best_area = a;
-                        best = i;
+        int cnt = 0;
+        {
+            // hand the four slots down as planned
+            struct Todo { int32_t node, parent; int slots; } todo[8];
+            int nt = 0;
+            const int j4 = (plan.dec[n] & 3u) + 1;
+            todo[nt++] = {nodes[n].rsIndex, n, 4 - j4};
+            todo[nt++] = {nodes[n].lsIndex, n, j4};
+            while(nt > 0) {
+                const Todo t = todo[--nt];
+                int a = 0, b = 0;  // slots of ls / rs when the node dissolves
+                if(!is_leaf(t.node) && t.slots >= 2) {
+                    const uint8_t d = plan.dec[t.node];
+                    if(t.slots == 2) {
+                        if(d & 4u) a = b = 1;
+                    } else {
+                        const unsigned d3 = (d >> 3) & 3u;
+                        if(d3 == 1) { a = 1; b = 2; }
+                        else if(d3 == 2) { a = 2; b = 1; }
+                        else if(d3 == 3) { a = 1; b = 1; }
                     }
                 }
-            if(best < 0) break;
-            const int32_t c = items[best].node;
-            for(int i = cnt; i > best + 1; i--) items[i] = items[i - 1];
-            items[best] = {nodes[c].lsIndex, c};
-            items[best + 1] = {nodes[c].rsIndex, c};
-            cnt++;
+                if(a == 0) {
+                    items[cnt++] = {t.node, t.parent};
+                } else {
+                    todo[nt++] = {nodes[t.node].rsIndex, t.node, b};
+                    todo[nt++] = {nodes[t.node].lsIndex, t.node, a};
+                }
+            }
         }
         const size_t k = wide_of[n];
         uint32_t refs[4];
@@ -238,14 +313,17 @@ uint32_t build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::v
                           std::vector<uint8_t> &wide_height) {
     const uint32_t stride = quantised ? 1u : 2u;
     wide_of.assign(n_nodes, REF_NONE);
+    CollapsePlan plan;
+    plan.cost.resize(3 * n_nodes);
+    plan.dec.assign(n_nodes, 0);
     std::vector<WideGroup> groups(disjoint ? roots.size() : 1);
     if(disjoint)
         parallel_items(roots.size(), layout_threads(), [&](size_t r) {
-            build_wide_group(nodes, n_nodes, &roots[r], 1, is_leaf, leaf_ref, leaf_box_of_parent, inner_kind, quantised, wide_of, groups[r]);
+            build_wide_group(nodes, n_nodes, &roots[r], 1, is_leaf, leaf_ref, leaf_box_of_parent, inner_kind, quantised, wide_of, plan, groups[r]);
         });
     else
         build_wide_group(nodes, n_nodes, roots.data(), roots.size(), is_leaf, leaf_ref, leaf_box_of_parent, inner_kind, quantised,
-                         wide_of, groups[0]);
+                         wide_of, plan, groups[0]);
     // merge: group g's wide node k becomes slot slot_base + stride * (first[g] + k)
     std::vector<size_t> first(groups.size() + 1, 0);
     for(size_t g = 0; g < groups.size(); g++) first[g + 1] = first[g] + groups[g].owner.size();
