@@ -25,7 +25,13 @@ enum : uint32_t {
     REF_TRIANGLE = 1u,     // mesh buffer, a TLeaf (which names its triangle)
     REF_SCENE_INNER = 2u,  // scene buffer, a TNode
     REF_INSTANCE = 3u,     // scene buffer, an InstAccel: instance index = (slot - inst_base) / 2
-    REF_INDEX_MASK = 0x3FFFFFFFu
+    REF_INDEX_MASK = 0x3FFFFFFFu,
+    // In a wide node, a triangle reference with this bit names TWO leaves, the TLeaf at the slot
+    // and the one behind it: the two children of one reference node (they share its box and take
+    // one child slot; that node itself never becomes a wide node).  The second is tested in the
+    // step after the first.  Mesh-buffer slots therefore stay below 2^29.
+    REF_PAIR = 0x20000000u,
+    REF_SLOT_MASK = 0x1FFFFFFFu
 };
 inline uint32_t make_ref(uint32_t kind, uint32_t index) { return (kind << 30) | index; }
 

