@@ -107,9 +107,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
                                                             unsigned *count_out, unsigned *shadow_queue,
                                                             unsigned *shadow_count) {
     __shared__ unsigned s_V[640];
+    const unsigned n = *count_in;
+    if(blockIdx.x * blockDim.x >= n && blockIdx.x != 0) return;  // (late bounces fill few blocks; block 0 books the counters)
     load_sobol_to_lds(s_V);
     const pt_params &P = dp.p;
-    const unsigned n = *count_in;
     const unsigned nthreads = gridDim.x * blockDim.x;
     const bool skyL = P.SkyboxLighting != 0, skyS = P.SkyboxSampling != 0;
 
