@@ -17,7 +17,10 @@
 namespace rta {
 namespace {
 
-constexpr int SHADE_BLOCK = 256;
+#ifndef RT_SHADE_BLOCK
+#define RT_SHADE_BLOCK 256
+#endif
+constexpr int SHADE_BLOCK = RT_SHADE_BLOCK;
 
 __device__ const unsigned g_sobol_table[640] = {
 #include "sobol_table.inc"
