@@ -199,3 +199,30 @@ def test_hostile_geometry(oracle_mod, gpu_ctx, fmt):
     _check(device.trace_rays(p, rays), ref)
     p.destroy()
     sb.release()
+
+
+def test_instances_rooted_inside_a_tree(casa, oracle_mod, gpu_ctx):
+    """meshIndex may name any node of the mesh BVH (pathtracing.glsl:254-264 just starts there):
+    an inner node of another mesh's tree, and a single leaf."""
+    import copy
+    from raytracing_amd import device
+    sd = copy.copy(casa)
+    inst = casa.instances.copy()
+    inner = np.flatnonzero(casa.mesh_nodes["tri"] < 0)
+    leaf = np.flatnonzero(casa.mesh_nodes["tri"] >= 0)
+    inst["meshIndex"][0] = inner[40]
+    inst["meshIndex"][1] = leaf[len(leaf) // 2]
+    sd.instances = inst
+    lo, hi = casa.world_box()
+    rays = random_rays(lo, hi, 1 << 18, 77)
+    sb = device.SceneBuffers(gpu_ctx, sd)
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    p.bind_scene(sb)
+    for fmt in (1, 0):
+        p.set_wide_nodes(fmt)
+        hits = device.trace_rays(p, rays)
+        ref, _ = oracle_mod.OracleScene(sd).intersect(rays)
+        _check(hits, ref)
+    assert p.stats()["reference_order_forced"] == 0
+    p.destroy()
+    sb.release()
