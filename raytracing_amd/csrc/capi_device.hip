@@ -359,7 +359,11 @@ int prepare_scene(pt_pass *p) {
 // per CU leaves a wave slot per SIMD to the kernels of the other draws, so that a latency-bound
 // shade kernel runs beside a traversal kernel, which is bound by vector-ALU issue: measured
 // +12 % (casa, 6 draws in flight) and +3 % (10 M triangles) over full grids.
-void set_draw_grid(pt_pass *p) { p->draw_blocks = p->ctx->num_cus * (p->n_lanes > 1 ? 3 : 8); }
+void set_draw_grid(pt_pass *p) {
+    const char *e = getenv("RTA_DRAW_BLOCKS_PER_CU");  // (tuning aid)
+    const int shared = e && atoi(e) > 0 && atoi(e) <= 8 ? atoi(e) : 3;
+    p->draw_blocks = p->ctx->num_cus * (p->n_lanes > 1 ? shared : 8);
+}
 
 // The ordered traversal is equivalent to the reference's order only when child boxes lie
 // inside their parents' boxes; other buffers are traced in the reference's order.

@@ -100,14 +100,14 @@ template <bool QUANT, class Source, class Sink>
 __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, Sink &sink, unsigned *next_ray,
                                               unsigned n_rays, uint2 *s_stack) {
 #ifndef RT_FAST_REFILL
-#define RT_FAST_REFILL 48
+#define RT_FAST_REFILL 40
 #endif
     constexpr int REFILL_BELOW = RT_FAST_REFILL;  // refill when fewer lanes than this still own a ray
 #ifndef RT_LEAF_BATCH
-#define RT_LEAF_BATCH 8
+#define RT_LEAF_BATCH 12
 #endif
 #ifndef RT_INST_BATCH
-#define RT_INST_BATCH 4
+#define RT_INST_BATCH 6
 #endif
 #ifndef RT_SERVE_ALL_BELOW
 #define RT_SERVE_ALL_BELOW 16
