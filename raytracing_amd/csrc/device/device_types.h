@@ -49,7 +49,7 @@ static_assert(sizeof(TNode) == 64, "traversal node is 64 bytes");
 // references.  A child that is a triangle carries the box of its PARENT in the reference tree
 // (the reference tests no box of the leaf itself); an absent child is REF_NONE.
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
-struct alignas(128) WNode {
+struct alignas(64) WNode {  // (placed at even slots, so 128-byte aligned in the buffers)
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
     uint32_t c[4];

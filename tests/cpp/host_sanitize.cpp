@@ -1,0 +1,104 @@
+// Drives the host half of the library (BVH build, scene level, traversal re-layout and its
+// checker, image quantisation) on random and degenerate inputs.  Meant to be built with
+// -fsanitize=address,undefined (tests/test_host_sanitizers.py): the checks are the sanitizers'.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "raytracing_amd.h"
+
+static int fails = 0;
+#define EXPECT(cond)                                                        \
+    do {                                                                    \
+        if(!(cond)) {                                                       \
+            fprintf(stderr, "%s:%d: %s: %s\n", __FILE__, __LINE__, #cond, pt_last_error()); \
+            fails++;                                                        \
+        }                                                                   \
+    } while(0)
+
+int main() {
+    std::mt19937 rng(3);
+    std::uniform_real_distribution<float> u(-1.0f, 1.0f);
+    const int tri_counts[] = {1, 2, 3, 257, 5000, 64};
+    const int n_mesh = 6;
+    std::vector<int32_t> tri_count(tri_counts, tri_counts + n_mesh);
+    size_t n_tris = 0, n_nodes = 0;
+    for(int c : tri_count) {
+        n_tris += c;
+        n_nodes += 2 * c - 1;
+    }
+    std::vector<float> tris(n_tris * 24, 0.0f);
+    for(size_t t = 0; t < n_tris; t++) {
+        const float scale = t < 6 ? 1e-6f : (t % 97 == 0 ? 1e5f : 1.0f);
+        const float cx = u(rng) * scale * 5, cy = u(rng) * scale * 5, cz = u(rng) * scale * 5;
+        for(int k = 0; k < 9; k++) tris[t * 24 + k] = (k % 3 == 0 ? cx : k % 3 == 1 ? cy : cz) + u(rng) * 0.1f * scale;
+        if(t % 50 == 7)  // a degenerate triangle and a duplicate of its predecessor
+            for(int k = 0; k < 9; k++) tris[t * 24 + k] = tris[(t - 1) * 24 + k];
+        tris[t * 24 + 11] = 1.0f;
+        tris[t * 24 + 14] = 1.0f;
+        tris[t * 24 + 17] = 1.0f;
+    }
+    std::vector<uint8_t> mesh_nodes(n_nodes * 48);
+    std::vector<float> root_box(n_mesh * 6);
+    std::vector<int32_t> siz(n_mesh), depth(n_mesh);
+    EXPECT(pt_host_build_mesh_bvh(tris.data(), tri_count.data(), n_mesh, 3, mesh_nodes.data(), root_box.data(), siz.data(),
+                                  depth.data()) == PT_OK);
+    const int n_inst = 9;
+    std::vector<float> l2w(n_inst * 16, 0.0f);
+    std::vector<int32_t> mesh_index(n_inst), material_ptr(n_inst);
+    for(int i = 0; i < n_inst; i++) {
+        float pos[3] = {u(rng) * 3, u(rng) * 3, u(rng) * 3}, rot[3] = {u(rng) * 180, u(rng) * 180, u(rng) * 180};
+        float scl[3] = {i == 7 ? -1.0f : 1.0f + u(rng) * 0.5f, 1.0f, i == 8 ? 1e-3f : 2.0f};
+        EXPECT(pt_host_transform_matrix(pos, rot, scl, &l2w[i * 16]) == PT_OK);
+        mesh_index[i] = i % n_mesh;
+        material_ptr[i] = i * 8;
+    }
+    std::vector<uint8_t> inst(n_inst * 112), scene_nodes((2 * n_inst - 1) * 48);
+    int32_t stats[2];
+    EXPECT(pt_host_build_scene(root_box.data(), siz.data(), depth.data(), n_mesh, l2w.data(), mesh_index.data(), material_ptr.data(),
+                               n_inst, inst.data(), scene_nodes.data(), stats) == PT_OK);
+    uint64_t counts[4];
+    for(int fmt = -1; fmt <= 1; fmt++)
+        EXPECT(pt_host_check_traversal_layout(mesh_nodes.data(), n_nodes, tris.data(), n_tris, scene_nodes.data(), 2 * n_inst - 1,
+                                              inst.data(), n_inst, fmt, counts) == PT_OK);
+    // an instance rooted inside a tree, one rooted at a leaf; then indices out of range
+    {
+        std::vector<uint8_t> inst2 = inst;
+        auto mesh_index_of = [&](int i) { return reinterpret_cast<int32_t *>(&inst2[i * 112 + 68]); };
+        *mesh_index_of(0) = n_mesh + 3;
+        *mesh_index_of(1) = (int32_t)n_nodes - 1;
+        for(int fmt = 0; fmt <= 1; fmt++)
+            EXPECT(pt_host_check_traversal_layout(mesh_nodes.data(), n_nodes, tris.data(), n_tris, scene_nodes.data(), 2 * n_inst - 1,
+                                                  inst2.data(), n_inst, fmt, counts) == PT_OK);
+        *mesh_index_of(2) = (int32_t)n_nodes;
+        EXPECT(pt_host_check_traversal_layout(mesh_nodes.data(), n_nodes, tris.data(), n_tris, scene_nodes.data(), 2 * n_inst - 1,
+                                              inst2.data(), n_inst, 1, counts) == PT_ERR_INVALID);
+    }
+    // corrupted node boxes and child links
+    {
+        std::vector<uint8_t> bad = mesh_nodes;
+        float *f = reinterpret_cast<float *>(&bad[(size_t)(n_mesh + 40) * 48]);
+        f[0] = NAN;
+        f[5] = INFINITY;
+        f = reinterpret_cast<float *>(&bad[(size_t)(n_mesh + 90) * 48]);
+        f[1] = -3e38f;
+        f[5] = 3e38f;
+        for(int fmt = 0; fmt <= 1; fmt++)
+            EXPECT(pt_host_check_traversal_layout(bad.data(), n_nodes, tris.data(), n_tris, scene_nodes.data(), 2 * n_inst - 1, inst.data(),
+                                                  n_inst, fmt, counts) == PT_OK);
+        int32_t *links = reinterpret_cast<int32_t *>(&bad[(size_t)3 * 48 + 32]);  // root of the 257-triangle mesh
+        links[0] = 1;  // a child before its parent
+        EXPECT(pt_host_check_traversal_layout(bad.data(), n_nodes, tris.data(), n_tris, scene_nodes.data(), 2 * n_inst - 1, inst.data(),
+                                              n_inst, 1, counts) == PT_ERR_INVALID);
+    }
+    // image quantisation with NaN / Inf / negative / huge values
+    {
+        std::vector<float> img = {NAN, INFINITY, -INFINITY, -1.0f, 0.0f, 0.5f, 1.0f, 1e30f, 0.999f, 2.0f, -0.0f, 1e-30f};
+        std::vector<uint8_t> px(img.size());
+        EXPECT(pt_host_quantize_image(img.data(), 2, 2, 3, px.data()) == PT_OK);
+    }
+    printf(fails ? "FAILED %d\n" : "host sanitize run ok\n", fails);
+    return fails ? 1 : 0;
+}
