@@ -99,6 +99,58 @@ int main() {
         std::vector<uint8_t> px(img.size());
         EXPECT(pt_host_quantize_image(img.data(), 2, 2, 3, px.data()) == PT_OK);
     }
+    // Radiance codec: round trip, then every truncation of the encoded file and random garbage
+    {
+        const int w = 24, h = 9;
+        std::vector<float> rgb(w * h * 3);
+        for(float &x : rgb) x = std::fabs(u(rng)) * 40.0f;
+        rgb[5] = 0.0f;
+        rgb[6] = 1e-30f;
+        const int64_t need = pt_host_rgbe_encode(rgb.data(), w, h, nullptr, 0);
+        EXPECT(need > 0);
+        std::vector<uint8_t> file((size_t)need);
+        EXPECT(pt_host_rgbe_encode(rgb.data(), w, h, file.data(), file.size()) == need);
+        int32_t dw = 0, dh = 0;
+        EXPECT(pt_host_rgbe_decode(file.data(), file.size(), &dw, &dh, nullptr) == PT_OK && dw == w && dh == h);
+        std::vector<float> back(w * h * 3);
+        EXPECT(pt_host_rgbe_decode(file.data(), file.size(), &dw, &dh, back.data()) == PT_OK);
+        for(size_t cut = 0; cut < file.size(); cut += 7) {
+            std::vector<uint8_t> part(file.begin(), file.begin() + cut);  // exact-size buffer: overreads are seen
+            (void)pt_host_rgbe_decode(part.data(), part.size(), &dw, &dh, dw == w && dh == h ? back.data() : nullptr);
+        }
+        for(int rep = 0; rep < 200; rep++) {
+            std::vector<uint8_t> junk(file.begin(), file.end());
+            for(int k = 0; k < 8; k++) junk[rng() % junk.size()] = (uint8_t)rng();
+            int32_t jw = 0, jh = 0;
+            if(pt_host_rgbe_decode(junk.data(), junk.size(), &jw, &jh, nullptr) == PT_OK && (size_t)jw * jh <= (size_t)w * h)
+                (void)pt_host_rgbe_decode(junk.data(), junk.size(), &jw, &jh, back.data());
+        }
+        // sky cache of that image, of a black one and of one with a NaN
+        std::vector<float> cache(w * h * 3);
+        double sum = 0;
+        EXPECT(pt_host_sky_cache(rgb.data(), w, h, cache.data(), &sum) == PT_OK && sum > 0);
+        std::vector<float> black(w * h * 3, 0.0f);
+        (void)pt_host_sky_cache(black.data(), w, h, cache.data(), &sum);
+        rgb[10] = NAN;
+        (void)pt_host_sky_cache(rgb.data(), w, h, cache.data(), &sum);
+    }
+    // PNG writer
+    {
+        std::vector<uint8_t> px(5 * 3 * 4);
+        for(uint8_t &b : px) b = (uint8_t)rng();
+        for(int ch : {1, 3, 4}) EXPECT(pt_host_write_png("/tmp/host_sanitize_out.png", 5, 3, ch, px.data()) == PT_OK);
+        EXPECT(pt_host_write_png("/nonexistent-dir/x.png", 5, 3, 3, px.data()) != PT_OK);
+        EXPECT(pt_host_write_png("/tmp/host_sanitize_out.png", 5, 3, 2, px.data()) != PT_OK);
+    }
+    // matrices
+    {
+        float m[16], inv[16], prod[16], proj[16];
+        float pos[3] = {1, 2, 3}, rot[3] = {10, 20, 30}, scl[3] = {1, 2, 0};  // singular
+        EXPECT(pt_host_transform_matrix(pos, rot, scl, m) == PT_OK);
+        (void)pt_host_mat4_inverse(m, inv);
+        EXPECT(pt_host_mat4_mul(m, inv, prod) == PT_OK);
+        EXPECT(pt_host_camera_projection(1.0f, 1000.0f, 640, 480, proj) == PT_OK);
+    }
     printf(fails ? "FAILED %d\n" : "host sanitize run ok\n", fails);
     return fails ? 1 : 0;
 }
