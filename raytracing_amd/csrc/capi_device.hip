@@ -820,6 +820,15 @@ int pt_pass_draw(pt_pass *p) {
     pt_pass::Lane &L = p->lanes[p->next_lane];
     p->next_lane = (p->next_lane + 1) % p->n_lanes;
     if((rc = prepare_lane(p, L, n_shadow))) return rc;
+    // A draw that finds no other draw of this pass on the device takes the full grid (a caller
+    // that waits for every frame should not pay for leaving room to draws that never come).
+    int grid = p->draw_blocks;
+    if(p->n_lanes > 1) {
+        bool alone = true;
+        for(int k = 0; k < p->n_lanes && alone; k++)
+            if(p->lanes[k].done && hipEventQuery(p->lanes[k].done) == hipErrorNotReady) alone = false;
+        if(alone) grid = p->trace_blocks;
+    }
 
     DrawParams dp;
     memset(&dp, 0, sizeof dp);
@@ -885,12 +894,12 @@ int pt_pass_draw(pt_pass *p) {
     auto extend = [&](int dep, const unsigned *q) {
         ScopedTimer t(p, K_EXTEND);
         if(ordered) {
-            launch_extend_fast(s, fsc, p->draw_blocks, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, qr,
+            launch_extend_fast(s, fsc, grid, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, qr,
                                cnt + CNT_REDO + dep);
             // near-ties in t: decided by the reference-order traversal
             launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep, true);
         } else {
-            launch_extend(s, sc, p->draw_blocks, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, false);
+            launch_extend(s, sc, grid, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, false);
         }
     };
     if(!raster_first) extend(0, q_in);  // with RasterizaionFor1st the first hit comes from the raster images
@@ -909,7 +918,7 @@ int pt_pass_draw(pt_pass *p) {
         if(dep < P.MAX_DEPTH) {
             if(merged) {
                 ScopedTimer t(p, K_TRACE);
-                launch_path_trace_fast(s, fsc, p->draw_blocks, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, dp.rays,
+                launch_path_trace_fast(s, fsc, grid, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, dp.rays,
                                        dp.hits, dp.shadow, (int)npix, cnt + CNT_NEXT + 2 * dep + 1, qr, cnt + CNT_REDO + dep + 1, dp.thr,
                                        dp.acc, dp.stats + 2);
                 launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep + 1, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep + 1, true);
@@ -917,10 +926,10 @@ int pt_pass_draw(pt_pass *p) {
                 {
                     ScopedTimer t(p, K_SHADOW);
                     if(ordered && n_shadow == 1)
-                        launch_shadow_fast(s, fsc, p->draw_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, (int)npix,
+                        launch_shadow_fast(s, fsc, grid, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, (int)npix,
                                            cnt + CNT_NEXT + 2 * dep + 1);
                     else
-                        launch_shadow(s, sc, p->draw_blocks, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
+                        launch_shadow(s, sc, grid, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
                                       cnt + CNT_NEXT + 2 * dep + 1);
                 }
                 extend(dep + 1, q_out);
