@@ -202,7 +202,9 @@ int pt_pass_set_wide_nodes(pt_pass *pass, int format);
  * outputs are the same as with 1: the last-write outputs and the running mean are applied in
  * call order.  Every other call on the context (uploads, downloads, pt_ctx_synchronize,
  * pt_pass_stats ...) waits for the draws issued before it.  Each draw in flight holds about
- * 210 bytes per pixel of path state.  While profiling is enabled (pt_pass_set_profiling) the
+ * 210 bytes per pixel of path state.  More than three need more hardware queues than HIP's
+ * default of 4 per process (GPU_MAX_HW_QUEUES, set before the process first touches the GPU).
+ * While profiling is enabled (pt_pass_set_profiling) the
  * per-kernel times of overlapping draws include each other: profile with 1. */
 int pt_pass_set_pipeline(pt_pass *pass, int draws_in_flight);
 
