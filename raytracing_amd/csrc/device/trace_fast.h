@@ -49,7 +49,10 @@
 namespace rta {
 
 constexpr int FAST_BLOCK = 256;
-constexpr int FAST_LDS_STACK = 8;  // 8-byte entries per lane in LDS: 16 KiB per block
+#ifndef RT_FAST_LDS_STACK
+#define RT_FAST_LDS_STACK 16
+#endif
+constexpr int FAST_LDS_STACK = RT_FAST_LDS_STACK;  // 8-byte entries per lane in LDS: 2 KiB per entry and block
 
 struct FastScene {
     const char *mesh_buf;    // TNodes and TLeafs of all meshes (64-byte slots)
