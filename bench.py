@@ -95,7 +95,7 @@ def main():
 
     wl = args.workload
     steps = args.steps if args.steps is not None else (64 if wl == "casa_pt" else (8 if wl == "casa_isect" else 16))
-    warmup = args.warmup if args.warmup is not None else (4 if wl != "casa_isect" else 2)
+    warmup = args.warmup if args.warmup is not None else {"casa_pt": 16, "casa_isect": 2}.get(wl, 4)
 
     t_setup = time.time()
     # large synthetic scenes take minutes to generate and build: say so now and then
