@@ -226,3 +226,47 @@ def test_instances_rooted_inside_a_tree(casa, oracle_mod, gpu_ctx):
     assert p.stats()["reference_order_forced"] == 0
     p.destroy()
     sb.release()
+
+
+def test_random_scene_sweep(oracle_mod, gpu_ctx):
+    """Twelve seeded random scenes (1..5 meshes of 1..2000 triangles at magnitudes 1e-4..1e4,
+    extra instances with random rotations, non-uniform and mirrored scales), rays aimed at the
+    instances and rays from far outside: ids, t, u, v word for word in both node formats."""
+    from raytracing_amd import device, scene
+    from conftest import _soup
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    total_hits = 0
+    for seed in range(12):
+        rng = np.random.default_rng(1000 + seed)
+        b = scene.SceneBuilder()
+        ids = []
+        for _ in range(int(rng.integers(1, 6))):
+            mag = 10.0 ** rng.uniform(-4, 4)
+            ids.append(b.add_mesh(_soup(rng, int(rng.integers(1, 2001)), mag, rng.uniform(-3, 3, 3) * mag)))
+            b.add_instance(ids[-1])
+        for _ in range(int(rng.integers(0, 5))):
+            s = 10.0 ** rng.uniform(-2, 2, 3) * rng.choice([-1.0, 1.0], 3)
+            b.add_instance(int(rng.choice(ids)), scene.transform_matrix(tuple(rng.uniform(-2, 2, 3)), tuple(rng.uniform(0, 360, 3)), tuple(s)))
+        sd = b.finish()
+        rays = []
+        for k in range(len(sd.instances)):
+            leaf = np.flatnonzero(sd.scene_nodes["inst"] == k)[0]
+            lo, hi = sd.scene_nodes["aa"][leaf][:3].astype(np.float64), sd.scene_nodes["bb"][leaf][:3].astype(np.float64)
+            ext = np.maximum(hi - lo, 1e-30)
+            n = 4000
+            target = lo + rng.uniform(0, 1, (n, 3)) * ext
+            origin = (lo + hi) / 2 + rng.normal(0, 1, (n, 3)) * ext * rng.choice([0.3, 1.5, 50.0], (n, 1))
+            d = target - origin
+            d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-300)
+            rays.append(np.concatenate([origin, d], 1))
+        rays = np.ascontiguousarray(np.concatenate(rays), np.float32)
+        ref, _ = oracle_mod.OracleScene(sd).intersect(rays)
+        total_hits += int((ref["triangle"] >= 0).sum())
+        sb = device.SceneBuffers(gpu_ctx, sd)
+        p.bind_scene(sb)
+        for fmt in (0, 1):
+            p.set_wide_nodes(fmt)
+            _check(device.trace_rays(p, rays), ref)
+        assert p.stats()["reference_order_forced"] == 0
+        sb.release()
+    assert total_hits > 20000

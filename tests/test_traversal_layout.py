@@ -107,3 +107,32 @@ def test_malformed_buffers_are_refused(casa):
     inst["meshIndex"][0] = len(casa.mesh_nodes)
     rc, _, err = check_layout(casa, 1, instances=inst)
     assert rc != 0 and "out of range" in err
+
+
+def test_random_scenes_keep_every_reference_leaf_reachable():
+    """Property over seeded random scenes: any number of meshes of 1..400 triangles at magnitudes
+    from 1e-8 to 1e8, shifted up to 1e6 magnitudes away from the origin, instanced with random
+    rotations, non-uniform and mirrored scales: both node formats pass the independent check."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None, derandomize=True)
+    @given(seed=st.integers(0, 2**31 - 1), n_meshes=st.integers(1, 5), n_extra=st.integers(0, 4))
+    def prop(seed, n_meshes, n_extra):
+        rng = np.random.default_rng(seed)
+        sb = scene.SceneBuilder()
+        ids = []
+        for _ in range(n_meshes):
+            mag = 10.0 ** rng.uniform(-8, 8)
+            off = rng.uniform(-1, 1, 3) * mag * 10.0 ** rng.uniform(0, 6) * (rng.random() < 0.5)
+            ids.append(sb.add_mesh(_random_mesh(rng, int(rng.integers(1, 401)), mag, off)))
+            sb.add_instance(ids[-1])
+        for _ in range(n_extra):
+            s = 10.0 ** rng.uniform(-3, 3, 3) * rng.choice([-1.0, 1.0], 3)
+            sb.add_instance(int(rng.choice(ids)), scene.transform_matrix(tuple(rng.uniform(-5, 5, 3)), tuple(rng.uniform(0, 360, 3)), tuple(s)))
+        sd = sb.finish()
+        for fmt in (0, 1):
+            rc, counts, err = check_layout(sd, fmt)
+            assert rc == 0, (seed, fmt, err)
+            assert counts[2] >= len(sd.triangles)
+
+    prop()
