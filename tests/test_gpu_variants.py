@@ -221,3 +221,21 @@ def test_material_parameter_extremes(small_sky, oracle_mod, gpu_ctx):
     assert len(seen) >= len(cases) - 2 and cnt["rays_extend"] > 160 * 90
     p.destroy()
     sb.release()
+
+
+def test_unusual_environment_maps(mixed_scene, oracle_mod, gpu_ctx):
+    """Environment maps the importance-sampling cache has to cope with (src/texture/HDRTexture.cpp,
+    shader/pathtracing.glsl:414-470): white noise at an odd size, a black map with one bright texel
+    (every sky sample lands on it), a 2x1 map, and a map with values up to 1e6."""
+    from raytracing_amd import scene
+    rng = np.random.default_rng(8)
+    noise = rng.random((19, 37, 3), dtype=np.float32) * 3.0
+    spot = np.zeros((32, 64, 3), np.float32)
+    spot[9, 41] = (900.0, 800.0, 700.0)
+    two = np.array([[[0.2, 0.3, 0.9], [1.5, 1.2, 0.4]]], np.float32)
+    wide = (10.0 ** rng.uniform(-6, 6, (16, 32, 1))).astype(np.float32) * np.ones((1, 1, 3), np.float32)
+    for rgb in (noise, spot, two, wide):
+        sky = scene.Sky(rgb)
+        out, ref, st, cnt = run(gpu_ctx, oracle_mod, mixed_scene, sky, 96, 54, [1, 1], max_depth=3)
+        check(out, ref)
+        assert cnt["rays_shadow"] > 0
