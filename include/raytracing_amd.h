@@ -233,6 +233,18 @@ typedef struct pt_hit {
     float u, v;       /* barycentrics of vertices 1 and 2                        */
 } pt_hit;
 int pt_pass_intersect(pt_pass *pass, const pt_buf *rays, size_t n, pt_buf *hits);
+/* pt_pass_intersect without any allocation.  No counterpart in the reference: it is for callers
+ * that cannot allocate device memory where they call the library (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  Same kernels and results as
+ * pt_pass_intersect; the counters, the list of rays left to the reference-order traversal and
+ * the stack spill area live in a file-scope device array of 28 MiB that every GPU the library
+ * runs on holds until the process ends.  Limits, reported as errors: at most 1 048 576 rays
+ * per call; trees whose traversal needs more than 48 spill entries per ray are refused
+ * (PT_ERR_UNSUPPORTED); the traversal arrays of the bound scene must be current, i.e.
+ * pt_pass_intersect or pt_pass_draw ran since the scene buffers last changed (PT_ERR_STATE
+ * otherwise: laying them out allocates).  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two contexts, two host threads) race. */
+int pt_pass_intersect_noalloc(pt_pass *pass, const pt_buf *rays, size_t n, pt_buf *hits);
 
 /* ---- post-processing: the consumers of the pass's outputs that produce a viewable image ----
  * All buffers hold floats, 3 per pixel unless stated; npix is taken from the buffer sizes,

@@ -24,6 +24,7 @@ struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
+    void *scratch = nullptr;  // this device's copy of the file-scope scratch array (pt_pass_intersect_noalloc)
     uint64_t next_handle = 1;
     std::unordered_map<uint64_t, pt_tex *> textures;
     // Draws run on streams of their own (pt_pass::lanes).  Each leaves its completion event
@@ -101,6 +102,24 @@ const int OUT_SLOTS[7] = {PT_OUT_ALBEDO, PT_OUT_MOTION, PT_OUT_DEPTH, PT_OUT_NOR
 const int OUT_CHANNELS[7] = {3, 2, 1, 3, 1, 3, 3};
 
 }  // namespace
+
+// ---- scratch of pt_pass_intersect_noalloc ------------------------------------------------
+// One array per GPU the library runs on, held until the process ends:
+//   [0, 256)                    the three counter words of a call (next ray, redo count, next redo ray)
+//   [256, 256 + 4 * MAX_RAYS)   ray indices the ordered traversal leaves to the reference-order one
+//   then                        stack spill area, [depth][thread] entries of 8 bytes
+// `scratch` is the host-side stand-in of the symbol, not a device address: host code only ever
+// uses the address hipGetSymbolAddress returned for the current device (g_scratch_ptr).
+constexpr size_t NOALLOC_MAX_RAYS = 1u << 20;
+constexpr int NOALLOC_BLOCKS = 256;       // persistent grid, 256 threads each (one block per CU)
+constexpr int NOALLOC_SPILL_DEPTH = 48;   // spill entries per thread beyond the LDS stack (casa's trees are bounded by 29)
+constexpr size_t NOALLOC_REDO_OFFSET = 256;
+constexpr size_t NOALLOC_SPILL_OFFSET = NOALLOC_REDO_OFFSET + NOALLOC_MAX_RAYS * sizeof(unsigned);
+constexpr size_t NOALLOC_SCRATCH_BYTES =
+    NOALLOC_SPILL_OFFSET + (size_t)NOALLOC_BLOCKS * 256 * NOALLOC_SPILL_DEPTH * sizeof(uint2);  // 28 MiB + 256 B
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static void *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
 
 struct pt_pass {
     pt_ctx *ctx = nullptr;
@@ -518,9 +537,18 @@ int pt_ctx_create(int device_id, pt_ctx **out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     if(std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(PT_ERR_UNSUPPORTED, std::string("pt_ctx_create: this library is built for gfx950 only, device is ") + prop.gcnArchName);
+    // each GPU holds its own copy of the scratch array at its own address: ask once per device, with it current
+    if(device_id >= NOALLOC_MAX_DEVICES) return fail(PT_ERR_UNSUPPORTED, "pt_ctx_create: device index beyond " + std::to_string(NOALLOC_MAX_DEVICES - 1));
+    if(!g_scratch_ptr[device_id]) {
+        void *sp = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+        if(!sp) return fail(PT_ERR_HIP, "pt_ctx_create: hipGetSymbolAddress returned no address for the scratch array");
+        g_scratch_ptr[device_id] = sp;
+    }
     pt_ctx *c = new pt_ctx;
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
+    c->scratch = g_scratch_ptr[device_id];
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if(e != hipSuccess) {
         delete c;
@@ -1083,6 +1111,56 @@ int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
             launch_intersect(s, sc, (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n, nullptr, nullptr,
                              static_cast<pt_hit *>(hits->dptr), cnt + CNT_INTERSECT, nullptr);
         }
+    }
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+// pt_pass_intersect for callers that must not allocate: every byte of device memory beyond the
+// caller's rays and hits comes from this GPU's copy of the file-scope scratch array; no
+// hipMalloc / hipFree, no event creation.  Same kernels, same results.
+int pt_pass_intersect_noalloc(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
+    if(!p || !rays || !hits) return fail(PT_ERR_INVALID, "pt_pass_intersect_noalloc: null argument");
+    if(rays->ctx != p->ctx || hits->ctx != p->ctx) return fail(PT_ERR_INVALID, "pt_pass_intersect_noalloc: buffers belong to another context");
+    if(n > NOALLOC_MAX_RAYS)
+        return fail(PT_ERR_INVALID, "pt_pass_intersect_noalloc: " + std::to_string(n) + " rays exceed the limit of " +
+                                        std::to_string(NOALLOC_MAX_RAYS) + " per call (use pt_pass_intersect, or several calls)");
+    if(rays->bytes < n * 6 * sizeof(float)) return fail(PT_ERR_INVALID, "pt_pass_intersect_noalloc: ray buffer holds fewer than n rays");
+    if(hits->bytes < n * sizeof(pt_hit)) return fail(PT_ERR_INVALID, "pt_pass_intersect_noalloc: hit buffer holds fewer than n records");
+    pt_ctx *ctx = p->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // the traversal arrays must be current: building them allocates
+    if(!p->mesh_level_valid || !p->scene_level_valid || !p->d_mesh_buf.p || !p->d_scene_buf.p || slot_changed(p, PT_SLOT_TRIANGLE) ||
+       slot_changed(p, PT_SLOT_MESH_BVH) || slot_changed(p, PT_SLOT_INSTANCE_INFO) || slot_changed(p, PT_SLOT_SCENE_BVH))
+        return fail(PT_ERR_STATE, "pt_pass_intersect_noalloc: the bound scene has not been laid out for traversal yet (or has changed); "
+                                  "call pt_pass_intersect or pt_pass_draw once first");
+    if(p->spill_depth > NOALLOC_SPILL_DEPTH)
+        return fail(PT_ERR_UNSUPPORTED, "pt_pass_intersect_noalloc: this scene's trees need " + std::to_string(p->spill_depth) +
+                                            " spill entries per ray, the scratch array holds " + std::to_string(NOALLOC_SPILL_DEPTH));
+    if(!ctx->scratch) return fail(PT_ERR_STATE, "pt_pass_intersect_noalloc: no scratch address for this device");
+    hits->version++;
+    hits->shadow_valid = false;
+    if(n == 0) return PT_OK;
+    JOIN_TRY(ctx);
+    char *base = static_cast<char *>(ctx->scratch);  // the device address, never the symbol's name
+    unsigned *cnt = reinterpret_cast<unsigned *>(base);
+    unsigned *redo = reinterpret_cast<unsigned *>(base + NOALLOC_REDO_OFFSET);
+    void *spill = base + NOALLOC_SPILL_OFFSET;
+    hipStream_t s = ctx->stream;
+    // the array keeps the last call's contents: the counters must start at zero
+    HIP_TRY(hipMemsetAsync(cnt, 0, NOALLOC_REDO_OFFSET, s));
+    long long blocks = ((long long)n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    if(blocks > NOALLOC_BLOCKS) blocks = NOALLOC_BLOCKS;
+    const int redo_blocks = p->redo_blocks < NOALLOC_BLOCKS ? p->redo_blocks : NOALLOC_BLOCKS;
+    const TraceScene sc = make_trace_scene(p, spill);
+    if(use_ordered(p)) {
+        launch_intersect_fast(s, make_fast_scene(p, spill), (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n,
+                              static_cast<pt_hit *>(hits->dptr), cnt, redo, cnt + 1);
+        launch_intersect(s, sc, redo_blocks, static_cast<const float *>(rays->dptr), (unsigned)n, redo, cnt + 1,
+                         static_cast<pt_hit *>(hits->dptr), cnt + 2, static_cast<unsigned long long *>(p->d_stats.p) + 4);
+    } else {
+        launch_intersect(s, sc, (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n, nullptr, nullptr,
+                         static_cast<pt_hit *>(hits->dptr), cnt, nullptr);
     }
     HIP_TRY(hipGetLastError());
     return PT_OK;

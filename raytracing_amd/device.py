@@ -230,6 +230,10 @@ class PathTracingPass:
     def intersect(self, rays_buf, n, hits_buf):
         check(lib.pt_pass_intersect(self.h, rays_buf.h, n, hits_buf.h))
 
+    def intersect_noalloc(self, rays_buf, n, hits_buf):
+        """pt_pass_intersect_noalloc: the same closest hits, with no device allocation in the call."""
+        check(lib.pt_pass_intersect_noalloc(self.h, rays_buf.h, n, hits_buf.h))
+
     def stats(self, reset=False):
         s = PtStats()
         check(lib.pt_pass_stats(self.h, C.byref(s), int(reset)))
