@@ -13,8 +13,15 @@
  *   - plain pointers and sizes only; handles are opaque.
  *   - one context per GPU; calls on a context are serialised by the caller, as the
  *     reference's single GL thread serialises its own (main.cpp:153-354).
- *   - draw / intersect / uploads are asynchronous on the context's stream;
- *     pt_buf_download and pt_ctx_synchronize wait for it.
+ *   - draw / intersect are asynchronous.  Draws run on internal streams of the pass; every
+ *     other call of the library, pt_ctx_stream included, first orders the context's main
+ *     stream behind the draws issued so far.  pt_buf_download and pt_ctx_synchronize wait
+ *     for everything.  Work of the caller's own (events, kernels or collectives on
+ *     pt_buf_device_ptr memory) must be queued on the stream pt_ctx_stream returned AFTER
+ *     the draws it depends on were issued, or follow pt_ctx_synchronize.
+ *   - a traversal that runs out of stack (never with arrays made by the reference's builder,
+ *     whose tree heights size the stack) is reported as PT_ERR_STATE by the next call that
+ *     waits for the device: pt_ctx_synchronize, pt_buf_download, pt_pass_stats, pt_pass_profile.
  *   - the host-side helpers (pt_host_*) never touch a GPU.
  */
 #ifndef RAYTRACING_AMD_H
@@ -48,7 +55,10 @@ const char *pt_version(void);
 int pt_ctx_create(int device_id, pt_ctx **out);
 int pt_ctx_destroy(pt_ctx *ctx);
 int pt_ctx_synchronize(pt_ctx *ctx);
-/* the hipStream_t all work of this context is queued on (for event timing by callers) */
+/* The context's main hipStream_t, ordered behind every draw issued so far by this very call
+ * (draws run on streams of their own): what the caller queues on it afterwards -- timing
+ * events, copies, kernels, collectives -- runs after those draws.  Call it again after later
+ * draws.  NULL on failure. */
 void *pt_ctx_stream(pt_ctx *ctx);
 
 /* ---- buffers: SSBOBuffer<T>, src/SSBOBuffer.h:19-150 ------------------------------- */

@@ -50,6 +50,10 @@ static int ctx_join(pt_ctx *ctx) {
         if(_rc) return _rc;                 \
     } while(0)
 
+// Reports (once) a traversal-stack overflow of any pass of the context; to be called where the
+// device has just been waited for.
+static int ctx_check_overflow(pt_ctx *ctx);
+
 struct pt_buf {
     pt_ctx *ctx = nullptr;
     void *dptr = nullptr;
@@ -165,7 +169,12 @@ struct pt_pass {
     int next_lane = 0;
     hipEvent_t last_gbuf = nullptr, last_fin = nullptr;  // of the previous draw; null before the first
     hipStream_t cur_stream = nullptr;                    // stream the ScopedTimer records on
-    DeviceArray d_counters, d_stats, d_err;
+    DeviceArray d_counters, d_stats, d_err;  // d_err: traversal counters of RT_TRACE_STATS builds (bytes 16..47)
+    // Stack-overflow flag of the traversal kernels, in pinned host memory the device writes to
+    // directly (it is written only when a ray runs out of stack, i.e. never in a healthy run), so
+    // that every call that waits for the device can look at it without a copy.
+    unsigned *h_err = nullptr;  // host address
+    unsigned *d_err_flag = nullptr;  // the same word as the device sees it
     int trace_blocks = 0;   // persistent grid of a stand-alone launch (pt_pass_intersect); also sizes the spill areas
     int draw_blocks = 0;    // persistent grid of the trace launches of a draw
     int redo_blocks = 0;  // grid of the (small) reference-order launches behind the ordered ones
@@ -176,6 +185,19 @@ struct pt_pass {
     std::vector<hipEvent_t> event_pool;
     pt_profile prof;
 };
+
+static int ctx_check_overflow(pt_ctx *ctx) {
+    bool hit = false;
+    for(pt_pass *p : ctx->passes)
+        if(p->h_err && *static_cast<volatile unsigned *>(p->h_err)) {
+            *static_cast<volatile unsigned *>(p->h_err) = 0u;
+            hit = true;
+        }
+    if(hit)
+        return fail(PT_ERR_STATE, "traversal stack overflow: a ray needed more deferred nodes than the stack holds; "
+                                  "results of the calls since the last successful synchronisation are incomplete");
+    return PT_OK;
+}
 
 namespace {
 
@@ -327,11 +349,15 @@ int prepare_scene(pt_pass *p) {
             p->scene_level.max_stack = sl.max_stack;
             p->scene_level.nested = sl.nested;
             int need = sl.max_stack + 2 - (LDS_STACK < FAST_LDS_STACK ? LDS_STACK : FAST_LDS_STACK);
-            if(need < 0) need = 0;
-            if(need > p->spill_depth || !p->d_spill.p) {
+            if(need < 4) need = 4;
+            // (test aid: a cap below what the trees need makes deep rays overflow, which must be reported)
+            const char *cap_env = getenv("RTA_SPILL_DEPTH_CAP");
+            const bool capped = cap_env && *cap_env && atoi(cap_env) >= 0 && atoi(cap_env) < need;
+            if(capped) need = atoi(cap_env);
+            if(capped ? need != p->spill_depth || !p->d_spill.p : need > p->spill_depth || !p->d_spill.p) {
                 JOIN_TRY(ctx);
                 HIP_TRY(hipStreamSynchronize(ctx->stream));
-                p->spill_depth = need < 4 ? 4 : need;
+                p->spill_depth = need;
                 const size_t nthreads = (size_t)p->trace_blocks * TRACE_BLOCK;
                 if((rc = p->d_spill.ensure(nthreads * (size_t)p->spill_depth * sizeof(uint2)))) return rc;
             }
@@ -396,7 +422,8 @@ TraceScene make_trace_scene(pt_pass *p, void *spill = nullptr) {
     sc.hdr = p->scene_level.header;
     sc.spill = static_cast<uint2 *>(spill ? spill : p->d_spill.p);
     sc.spill_depth = p->spill_depth;
-    sc.error_flag = static_cast<unsigned *>(p->d_err.p);
+    sc.error_flag = p->d_err_flag;
+    sc.stats_dbg = static_cast<unsigned *>(p->d_err.p);
     return sc;
 }
 
@@ -457,7 +484,8 @@ FastScene make_fast_scene(pt_pass *p, void *spill = nullptr) {
     sc.hdr = p->scene_level.header;
     sc.spill = static_cast<uint2 *>(spill ? spill : p->d_spill.p);
     sc.spill_depth = p->spill_depth;
-    sc.error_flag = static_cast<unsigned *>(p->d_err.p);
+    sc.error_flag = p->d_err_flag;
+    sc.stats_dbg = static_cast<unsigned *>(p->d_err.p);
     return sc;
 }
 
@@ -573,10 +601,17 @@ int pt_ctx_synchronize(pt_ctx *ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
     JOIN_TRY(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return PT_OK;
+    return ctx_check_overflow(ctx);
 }
 
-void *pt_ctx_stream(pt_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+// Draws run on streams of their own; handing the main stream out orders it behind every draw
+// issued so far, so that work the caller queues on it (events, copies, kernels reading
+// pt_buf_device_ptr memory) sees finished frames.
+void *pt_ctx_stream(pt_ctx *ctx) {
+    if(!ctx) return nullptr;
+    if(hipSetDevice(ctx->device) != hipSuccess || ctx_join(ctx) != PT_OK) return nullptr;
+    return (void *)ctx->stream;
+}
 
 // ------------------------------------------------------------------------------- buffers
 int pt_buf_create(pt_ctx *ctx, size_t bytes, const void *host, pt_buf **out) {
@@ -675,7 +710,7 @@ int pt_buf_download(const pt_buf *buf, void *host, size_t bytes) {
     JOIN_TRY(buf->ctx);
     HIP_TRY(hipStreamSynchronize(buf->ctx->stream));
     if(bytes) HIP_TRY(hipMemcpy(host, buf->dptr, bytes, hipMemcpyDeviceToHost));
-    return PT_OK;
+    return ctx_check_overflow(buf->ctx);
 }
 
 size_t pt_buf_bytes(const pt_buf *buf) { return buf ? buf->bytes : 0; }
@@ -741,7 +776,18 @@ int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
     p->redo_blocks = ctx->num_cus;
     if(!rc) rc = p->d_counters.ensure(CNT_TOTAL * 4);
     if(!rc) rc = p->d_stats.ensure(8 * 8);
-    if(!rc) rc = p->d_err.ensure(64);  // word 0: stack overflow flag; bytes 16..47: traversal counters of RT_TRACE_STATS builds
+    if(!rc) rc = p->d_err.ensure(64);  // bytes 16..47: traversal counters of RT_TRACE_STATS builds
+    if(!rc) {
+        void *h = nullptr, *d = nullptr;
+        hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+        if(e == hipSuccess) {
+            memset(h, 0, 64);
+            e = hipHostGetDevicePointer(&d, h, 0);
+        }
+        if(e != hipSuccess) rc = fail(PT_ERR_HIP, std::string("hipHostMalloc (overflow flag): ") + hipGetErrorString(e));
+        p->h_err = static_cast<unsigned *>(h);
+        p->d_err_flag = static_cast<unsigned *>(d);
+    }
     if(!rc) {
         hipError_t e = hipMemsetAsync(p->d_stats.p, 0, 64, ctx->stream);
         if(e == hipSuccess) e = hipMemsetAsync(p->d_err.p, 0, 64, ctx->stream);
@@ -774,6 +820,7 @@ int pt_pass_destroy(pt_pass *p) {
     DeviceArray *arrs[] = {&p->d_mesh_buf, &p->d_scene_buf, &p->d_redo_isect,
                            &p->d_spill, &p->d_tex_table, &p->d_counters, &p->d_stats, &p->d_err};
     for(DeviceArray *a : arrs) a->release();
+    if(p->h_err) (void)hipHostFree(p->h_err);
     delete p;
     return PT_OK;
 }
@@ -1019,9 +1066,7 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     JOIN_TRY(pass->ctx);
     HIP_TRY(hipStreamSynchronize(pass->ctx->stream));
     unsigned long long raw[8];
-    unsigned err = 0;
     HIP_TRY(hipMemcpy(raw, pass->d_stats.p, sizeof raw, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&err, pass->d_err.p, 4, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     out->samples = raw[0];
     out->rays_extend = raw[1];
@@ -1036,11 +1081,7 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
         HIP_TRY(hipMemsetAsync(pass->d_stats.p, 0, 64, pass->ctx->stream));
         HIP_TRY(hipMemsetAsync(static_cast<char *>(pass->d_err.p) + 16, 0, 32, pass->ctx->stream));
     }
-    if(err) {
-        HIP_TRY(hipMemsetAsync(pass->d_err.p, 0, 16, pass->ctx->stream));
-        return fail(PT_ERR_STATE, "traversal stack overflow: a ray needed more deferred nodes than the tree height allows; results of the last calls are incomplete");
-    }
-    return PT_OK;
+    return ctx_check_overflow(pass->ctx);
 }
 
 int pt_pass_set_traversal(pt_pass *pass, int mode) {
@@ -1074,7 +1115,7 @@ int pt_pass_profile(pt_pass *pass, pt_profile *out, int reset) {
     collect_profile(pass);
     *out = pass->prof;
     if(reset) memset(&pass->prof, 0, sizeof pass->prof);
-    return PT_OK;
+    return ctx_check_overflow(pass->ctx);
 }
 
 int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {

@@ -22,7 +22,10 @@
 namespace rta {
 
 constexpr int TRACE_BLOCK = 256;
-constexpr int LDS_STACK = 12;  // deferred entries kept in LDS per lane (8 B each, 24 KiB per block)
+#ifndef RT_CORE_LDS_STACK
+#define RT_CORE_LDS_STACK 12
+#endif
+constexpr int LDS_STACK = RT_CORE_LDS_STACK;  // deferred entries kept in LDS per lane (8 B each, 24 KiB per block)
 constexpr float RT_INF = 1e18f;
 constexpr float RT_RAY_MINDIS = 0.001f;
 
@@ -32,7 +35,8 @@ struct TraceScene {
     SceneHeader hdr;
     uint2 *spill;            // [spill_depth][total threads of the launch]
     int spill_depth;
-    unsigned *error_flag;    // set to 1 when a ray needed more stack than LDS + spill
+    unsigned *error_flag;    // set to 1 when a ray needed more stack than LDS + spill (host-visible word)
+    unsigned *stats_dbg;     // RT_TRACE_STATS builds: counters from byte 16 on
 };
 
 struct LaneHit {

@@ -61,6 +61,7 @@ struct FastScene {
     uint2 *spill;
     int spill_depth;
     unsigned *error_flag;
+    unsigned *stats_dbg;
 };
 
 // 1/x to one ulp (v_rcp_f32), for the relaxed tests only.  With the subtraction and the
@@ -400,7 +401,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
         }
     }
 #ifdef RT_TRACE_STATS
-    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(sc.error_flag + 4);
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(sc.stats_dbg + 4);
     if(RT_TRACE_STATS == 2) {  // wave-level: iterations, iterations that ran the leaf / instance code
         atomicAdd(dbg + 0, st_iter);
         atomicAdd(dbg + 1, st_leaf_runs);

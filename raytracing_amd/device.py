@@ -251,7 +251,7 @@ class PathTracingPass:
         check(lib.pt_pass_set_wide_nodes(self.h, int(fmt)))
 
     def set_pipeline(self, draws_in_flight):
-        """How many draws may overlap on the device (1..8); outputs do not depend on it."""
+        """How many draws may overlap on the device (1..16); outputs do not depend on it."""
         check(lib.pt_pass_set_pipeline(self.h, int(draws_in_flight)))
 
     def set_profiling(self, enable=True):

@@ -142,3 +142,94 @@ def test_released_resources_are_unbound_not_dangling(gpu_ctx, casa, small_sky):
     p.destroy()
     sb.textures = sb.textures[1:]
     sb.release()
+
+
+def test_stream_handed_out_is_ordered_behind_draws(gpu_ctx, casa, small_sky):
+    """Draws run on streams of their own.  pt_ctx_stream() orders the context's main stream behind
+    the draws issued so far, so a device-to-device copy of an output queued on it right after
+    pt_pass_draw (no synchronisation in between) holds the finished frame."""
+    import ctypes
+    from raytracing_amd import device, scene
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    w, h = 640, 360
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    p.set_pipeline(3)
+    copies = {k: device.Buffer(gpu_ctx, nbytes=p.outputs[k].nbytes) for k in ("directLum", "indirectLum", "normal")}
+    for b in copies.values():
+        b.fill(-7.0)
+    jit = scene.mt19937_jitters(3)
+    gpu_ctx.synchronize()
+    for s in (1, 2, 3):
+        p.set_params(scene.make_params(w, h, scene.casa_camera(), small_sky, spp=s, max_depth=4, jitter=jit[s - 1]))
+        p.draw()
+    stream = gpu_ctx.stream   # joins the three draws
+    assert stream
+    for k, b in copies.items():
+        assert hip.hipMemcpyAsync(b.device_ptr, p.outputs[k].device_ptr, b.nbytes, 3, stream) == 0
+    assert hip.hipStreamSynchronize(stream) == 0
+    got = {k: b.download() for k, b in copies.items()}     # (download waits again; the copies are done by now)
+    ref = p.download()
+    for k in copies:
+        assert np.array_equal(got[k].view(np.uint32), ref[k].reshape(-1).view(np.uint32)), k
+    for b in copies.values():
+        b.release()
+    p.destroy()
+    sb.release()
+
+
+_OVERFLOW_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from raytracing_amd import _capi, device, scene
+casa = scene.casa_scene(sys.argv[1] + "/assets/casa_obj.glb")
+ctx = device.Context(0)
+lo, hi = casa.world_box()
+rays = scene.random_rays(lo, hi, 1 << 18, 5)
+sb = device.SceneBuffers(ctx, casa)
+rb = device.Buffer(ctx, rays)
+hb = device.Buffer(ctx, nbytes=len(rays) * device.HIT_DTYPE.itemsize)
+
+def reports(fn):
+    try:
+        fn()
+    except _capi.PtError as e:
+        assert "stack overflow" in str(e), str(e)
+        return True
+    return False
+
+for mode in (0, 1):
+    p = device.PathTracingPass(ctx, 16, 16)
+    p.bind_scene(sb)
+    p.set_traversal(mode)
+    p.intersect(rb, len(rays), hb)
+    assert reports(ctx.synchronize), "synchronize did not report (mode %d)" % mode
+    assert not reports(ctx.synchronize), "reported twice"
+    p.intersect(rb, len(rays), hb)
+    assert reports(lambda: hb.download(np.uint8)), "download did not report"
+    p.intersect(rb, len(rays), hb)
+    assert reports(p.stats), "stats did not report"
+    p.destroy()
+print("overflow reported")
+"""
+
+
+def test_stack_overflow_is_reported_by_the_calls_that_wait():
+    """A build of the library with three stack entries per ray in LDS (libraytracing_amd.smallstack.so,
+    made by __graft_entry__.build) and the spill area capped to nothing: deep rays run out of stack
+    in both traversals.  The kernels drop the entry (no out-of-bounds access) and raise a flag that
+    pt_ctx_synchronize / pt_buf_download / pt_pass_stats report, once.  Runs in a child process
+    because the library is chosen when raytracing_amd._capi is imported."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "raytracing_amd", "libraytracing_amd.smallstack.so")
+    assert os.path.exists(lib), "build it with __graft_entry__.build()"
+    env = dict(os.environ, RAYTRACING_AMD_LIB=lib, RTA_SPILL_DEPTH_CAP="0")
+    r = subprocess.run([sys.executable, "-c", _OVERFLOW_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0 and "overflow reported" in r.stdout, r.stdout + r.stderr
