@@ -27,7 +27,9 @@ import numpy as np
 
 # More hardware queues than HIP's default of 4, so that more draws can overlap on the device
 # (read once, when the HIP runtime starts: before torch is imported).
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 16:
+# A value the caller set is respected (and reported); under rocprofv3 the runtime has started
+# before this line runs, so the profiling scripts export the variable themselves.
+if not os.environ.get("GPU_MAX_HW_QUEUES", "").strip():
     os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -53,6 +55,11 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=6, help="draws in flight on the device (pt_pass_set_pipeline)")
     ap.add_argument("--wide-nodes", type=int, default=-1, choices=[-1, 0, 1],
                     help="node format of the ordered traversal (pt_pass_set_wide_nodes): -1 library default, 0 fp32, 1 quantised")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank draws --steps samples (N x steps in all); strong = --steps samples in all, "
+                         "sliced over the ranks (BASELINE config 4: a fixed 256-spp frame cut over 2/4/8 GPUs)")
+    ap.add_argument("--collective", default="capi", choices=["capi", "torch"],
+                    help="N > 1: combine through the library's own pt_pass_allreduce (RCCL, default) or through torch.distributed")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank control flow on ONE GPU: all ranks use device 0, gloo backend, collectives staged through the host")
     ap.add_argument("--dump", default=None, help="rank 0 writes the final output buffers to this .npz")
@@ -75,8 +82,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: start one rank per GPU as child processes (before anything here
+        # touches the GPU) and pass rank 0's JSON line through
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd).returncode)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d ...)" % (args.gpus, world, args.gpus, args.gpus))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -146,7 +166,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    result = {}
+    comm = collective = total_spp = None
     if wl == "casa_isect":
         lo, hi = sd.world_box()
         rays = scene.random_rays(lo, hi, args.rays, 7 + rank)
@@ -168,7 +188,7 @@ def main():
         prof = p.profile() if not args.no_profile else None
         dominant = ("intersect_fast_kernel + intersect_kernel", prof["intersect_ms"], prof["intersect_launches"], total_rays) if prof else None
     else:
-        total_spp = steps * world
+        total_spp = steps * world if args.scaling == "weak" else steps
         jit = scene.mt19937_jitters(total_spp)
         my_samples = multigpu.sample_slice(total_spp, rank, world)  # 1-based global sample indices
 
@@ -185,10 +205,32 @@ def main():
         note("warm-up draws queued")
         accum_mode = 1 if world > 1 else 0
         if world > 1:
+            # The combine: the library's own (RCCL through the C ABI) unless asked otherwise; RCCL takes one
+            # rank per GPU, so a rehearsal of several ranks on one GPU goes through torch.distributed (gloo).
+            collective = "torch.distributed" if (args.rehearse or args.collective == "torch") else "pt_pass_allreduce"
+            if collective == "pt_pass_allreduce":
+                try:
+                    comm = multigpu.make_comm(dist, ctx, rank, world)
+                except Exception as e:  # RCCL missing or refusing: say so and use the other path on every rank
+                    print("[bench] rank %d: pt_comm_create failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+                ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    if comm is not None:
+                        comm.destroy()
+                        comm = None
+                    collective = "torch.distributed (pt_comm_create failed)"
+
+            def combine(n_spp):
+                if comm is not None:
+                    multigpu.allreduce_outputs_capi(comm, p, n_spp)
+                    ctx.synchronize()
+                else:
+                    ctx.synchronize()
+                    multigpu.allreduce_outputs(torch, dist, p, npix, n_spp, dev_tensor, via_cpu=args.rehearse)
             # warm the collective up too (communicator, channels, staging buffers): its first use
             # costs far more than the later ones and does not belong to the frame
-            ctx.synchronize()
-            multigpu.allreduce_outputs(torch, dist, p, npix, max(warmup, 1) * world, dev_tensor, via_cpu=args.rehearse)
+            combine(max(warmup, 1) * world)
             for name in multigpu.ACCUMULATED:   # sums start from zero on every rank
                 p.outputs[name].fill(0.0)
         p.set_pipeline(args.pipeline)
@@ -198,8 +240,7 @@ def main():
         for s in my_samples:
             draw(s, accum_mode)
         if world > 1:
-            ctx.synchronize()
-            multigpu.allreduce_outputs(torch, dist, p, npix, total_spp, dev_tensor, via_cpu=args.rehearse)
+            combine(total_spp)
         barrier()
         dt = time.perf_counter() - t0
         note("timed region done")
@@ -258,7 +299,7 @@ def main():
             "warmup": warmup,
             "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "casa_obj.glb (reference demo scene) + procedural 2048x1024 sky" if wl != "synth_pt"
@@ -269,7 +310,10 @@ def main():
                        "resolution": [W, H] if wl != "casa_isect" else None,
                        "triangles": int(len(sd.triangles)), "instances": int(len(sd.instances)),
                        "draws_in_flight": args.pipeline if wl != "casa_isect" else None,
-                       "parallelism": "sample slicing x%d, one all-reduce" % world if world > 1 else "single GPU"},
+                       "parallelism": "sample slicing x%d, one all-reduce" % world if world > 1 else "single GPU",
+                       "collective": collective if wl != "casa_isect" else None,
+                       "total_spp": total_spp if wl != "casa_isect" else None,
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "msamples_per_s": total_samples / dt / 1e6,
             "retraced_fraction_of_extend_rays": (units_per_rank.get("retraced", 0) / units_per_rank["rays_extend"])
                                                 if units_per_rank.get("rays_extend") else None,
@@ -347,36 +391,60 @@ def main():
                     # sustain then; `achieved` above is per launch with one draw in flight, as events can time it.
                     whole = total_rays * b_ray / dt / 1e9
                     out["roofline"]["whole_step_with_draws_in_flight"] = {"achieved": whole, "frac": whole / HBM_PEAK_GBS}
-            # HBM bytes per launch of the same kernels, from the committed rocprofv3 --pmc passes
-            # (FETCH_SIZE + WRITE_SIZE; bench.py cannot collect counters on itself)
-            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % wl)
+            # What the same kernels physically do, from the committed rocprofv3 --pmc passes of this tree
+            # (bench.py cannot collect counters on itself): HBM bytes per launch (FETCH_SIZE + WRITE_SIZE),
+            # lanes active per vector instruction, vector-ALU issue occupancy, L2 hit rate.
+            from raytracing_amd.build import kernel_sources_digest
+            pmc_file = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_pmc_%s.json" % (r, wl)) for r in (3, 2, 1))
+                             if os.path.exists(f)), None)
             # (the committed passes are of the default configuration of each workload)
             default_cfg = args.depth == 8 and args.width is None and args.height is None and \
                 (wl != "synth_pt" or (args.tris == 10_000_000 and args.dielectric == 0.0 and args.textures == 0)) and \
                 (wl != "casa_isect" or args.rays == 1 << 24)
-            if "roofline" in out and os.path.exists(pmc_file) and default_cfg:
+            if "roofline" in out and pmc_file and default_cfg:
+                rf = out["roofline"]
                 pmc = json.load(open(pmc_file))
-                names = ["intersect_fast_kernel", "intersect_kernel"] if wl == "casa_isect" else \
-                        ["path_trace_fast_kernel", "extend_fast_kernel", "extend_kernel", "shadow_fast_kernel", "shadow_kernel"]
-                have = [n for n in names if n in pmc and "FETCH_SIZE" in pmc[n] and "WRITE_SIZE" in pmc[n]]
-                if have:
-                    # total bytes of those kernels over the profiled run / number of main launches
-                    tot = sum((pmc[n]["FETCH_SIZE"]["total"] + pmc[n]["WRITE_SIZE"]["total"]) * 1024.0 for n in have)
+                measured_on = pmc.get("_meta", {}).get("kernel_sources_sha256")
+                if measured_on != kernel_sources_digest():
+                    # counters of other kernels than the ones just timed say nothing about them
+                    rf["traffic_note"] = ("%s was measured on a different version of the kernel sources: traffic and the "
+                                          "counter-derived fields are left null (tools/run_pmc.sh refreshes it)" % os.path.basename(pmc_file))
+                    rf.update({"hbm_frac_measured": None, "lanes_active_per_valu_inst": None, "l2_hit": None, "valu_issue_busy": None})
+                else:
+                    names = ["intersect_fast_kernel", "intersect_kernel"] if wl == "casa_isect" else \
+                            ["path_trace_fast_kernel", "extend_fast_kernel", "extend_kernel", "shadow_fast_kernel", "shadow_kernel"]
+                    have = [n for n in names if n in pmc and "FETCH_SIZE" in pmc[n] and "WRITE_SIZE" in pmc[n]]
                     main = [n for n in have if n not in ("extend_kernel", "intersect_kernel")]
-                    n_launch = sum(pmc[n]["FETCH_SIZE"]["launches"] for n in main)
-                    out["roofline"]["traffic"] = tot / max(n_launch, 1)
-                    out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_file)
-                    out["roofline"]["algorithmic_bytes_per_launch"] = out["roofline"]["rays_per_launch"] * b_ray
-                    # vector-ALU issue occupancy of the main kernel in the same profile: wave instructions x 4 cycles
-                    # over (cycles x 1024 SIMDs); GRBM_GUI_ACTIVE sums the 8 XCDs
-                    m = pmc[main[0]] if main else None
-                    if m and "SQ_INSTS_VALU" in m and "GRBM_GUI_ACTIVE" in m:
-                        cyc = m["GRBM_GUI_ACTIVE"]["total"] / 8.0
-                        out["roofline"]["valu_issue_busy"] = m["SQ_INSTS_VALU"]["total"] * 4.0 / (cyc * 1024.0)
-                    out["roofline"]["note"] = ("achieved = the REFERENCE algorithm's bytes per ray (48-byte nodes in its visiting order, "
-                                               "counted by the oracle) x rays / kernel time; traffic = bytes this kernel really moved. "
-                                               "A fraction above 1 means the kernel answers the same queries with fewer bytes than that "
-                                               "algorithm needs; what then limits it is vector-ALU issue (valu_issue_busy).")
+                    if have and main:
+                        # total bytes of those kernels over the profiled run / number of main launches
+                        tot = sum((pmc[n]["FETCH_SIZE"]["total"] + pmc[n]["WRITE_SIZE"]["total"]) * 1024.0 for n in have)
+                        n_launch = sum(pmc[n]["FETCH_SIZE"]["launches"] for n in main)
+                        rf["traffic"] = tot / max(n_launch, 1)
+                        rf["traffic_source"] = "profiles/" + os.path.basename(pmc_file)
+                        rf["algorithmic_bytes_per_launch"] = rf["rays_per_launch"] * b_ray
+                        # the physical figure: bytes really moved per launch over this run's launch time
+                        rf["hbm_gbs_measured"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
+                        rf["hbm_frac_measured"] = rf["hbm_gbs_measured"] / HBM_PEAK_GBS
+                        m = pmc[main[0]]
+
+                        def tot_of(c):
+                            return sum(pmc[n][c]["total"] for n in main if c in pmc[n])
+                        if "SQ_INSTS_VALU" in m and "SQ_THREAD_CYCLES_VALU" in m:
+                            rf["lanes_active_per_valu_inst"] = tot_of("SQ_THREAD_CYCLES_VALU") / tot_of("SQ_INSTS_VALU")
+                        if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
+                            rf["l2_hit"] = tot_of("TCC_HIT_sum") / (tot_of("TCC_HIT_sum") + tot_of("TCC_MISS_sum"))
+                        if "SQ_INSTS_VALU" in m and "GRBM_GUI_ACTIVE" in m:
+                            # wave instructions x 4 cycles over (cycles x 1024 SIMDs); GRBM_GUI_ACTIVE sums the 8 XCDs
+                            rf["valu_issue_busy"] = tot_of("SQ_INSTS_VALU") * 4.0 / (tot_of("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)
+                        if "SQ_INSTS_SALU" in m and "SQ_INSTS_VALU" in m:
+                            rf["salu_per_valu_inst"] = tot_of("SQ_INSTS_SALU") / tot_of("SQ_INSTS_VALU")
+                        if rf["hbm_frac_measured"] < 0.3:
+                            rf["bound"] = "valu-issue/latency"
+                        rf["note"] = ("frac = the REFERENCE algorithm's bytes per ray (48-byte nodes in its visiting order, counted by "
+                                      "the oracle) x rays / kernel time / 8 TB/s; it is not bandwidth: the kernel answers the same queries "
+                                      "with far fewer bytes.  hbm_frac_measured = bytes the kernel really moved (PMC) / kernel time / 8 TB/s; "
+                                      "below 0.3 the kernel is bound by vector-ALU issue and latency (valu_issue_busy, "
+                                      "lanes_active_per_valu_inst of 64), not by HBM.")
             if prof:
                 out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "trace_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms")}
                 if "draws" in prof:
@@ -387,6 +455,8 @@ def main():
                         out["roofline"]["measured_on"] = "%d draws issued one at a time after the timed region" % prof["draws"]
         print(json.dumps(out), flush=True)
 
+    if wl != "casa_isect" and comm is not None:
+        comm.destroy()
     p.destroy()
     sb.release()
     ctx.destroy()

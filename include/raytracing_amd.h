@@ -256,6 +256,36 @@ int pt_pass_intersect(pt_pass *pass, const pt_buf *rays, size_t n, pt_buf *hits)
  * calls that overlap on one GPU (two contexts, two host threads) race. */
 int pt_pass_intersect_noalloc(pt_pass *pass, const pt_buf *rays, size_t n, pt_buf *hits);
 
+/* ---- multi-GPU: sample slicing over RCCL ------------------------------------------------
+ * No counterpart in the reference (single GPU, no collective anywhere).  What shards is the
+ * per-pixel mean over the samples of a frame (shader/pathtracing.glsl:657-670; the frame loop
+ * main.cpp:169-208): every rank (one per GPU) holds the whole scene and draws its slice of the
+ * global sample indices 1..SPP -- pt_params.currentspp carries the GLOBAL index, which seeds
+ * the sampler -- with accum_mode = 1, after zero-filling directLum, indirectLum and albedo
+ * (pt_buf_fill; the draw with currentspp == 1 overwrites instead).  pt_pass_allreduce then
+ * leaves the finished frame on every rank: one all-reduce(sum) over the nine accumulated floats
+ * per pixel, times 1 / total_spp, and one broadcast of the seven last-write floats per pixel
+ * (motion, depth, normal, instance index) from last_rank, the rank that drew sample SPP.
+ * Both run on the context's stream behind the draws issued so far; the call does not wait.
+ * RCCL (librccl.so.1) is opened at the first pt_comm_* call; without it they return
+ * PT_ERR_UNSUPPORTED.
+ *
+ * One process per GPU: rank 0 calls pt_comm_unique_id and hands the PT_COMM_ID_BYTES bytes to
+ * the other ranks by any host channel (MPI, a file, torch.distributed ...); every rank calls
+ * pt_comm_create (collective: returns when all ranks have called it).
+ * One process driving n GPUs: pt_comm_create_all over n contexts on n different GPUs, then
+ * pt_pass_allreduce_all with one pass per context, in rank order (rank k = ctxs[k]). */
+typedef struct pt_comm pt_comm;
+#define PT_COMM_ID_BYTES 128
+int pt_comm_unique_id(void *id_out);
+int pt_comm_create(pt_ctx *ctx, const void *id, int rank, int world, pt_comm **out);
+int pt_comm_create_all(pt_ctx *const *ctxs, int n, pt_comm **out);
+int pt_comm_destroy(pt_comm *comm);
+int pt_comm_rank(const pt_comm *comm);
+int pt_comm_world(const pt_comm *comm);
+int pt_pass_allreduce(pt_pass *pass, pt_comm *comm, uint32_t total_spp, int last_rank);
+int pt_pass_allreduce_all(pt_pass *const *passes, pt_comm *const *comms, int n, uint32_t total_spp, int last_rank);
+
 /* ---- post-processing: the consumers of the pass's outputs that produce a viewable image ----
  * All buffers hold floats, 3 per pixel unless stated; npix is taken from the buffer sizes,
  * which must agree.  Each call is queued behind the draws issued before it.

@@ -104,6 +104,14 @@ SIGNATURES = {
     "pt_pass_profile": (C.c_int, [C.c_void_p, C.POINTER(PtProfile), C.c_int]),
     "pt_pass_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pt_pass_intersect_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pt_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pt_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_void_pp]),
+    "pt_comm_create_all": (C.c_int, [c_void_pp, C.c_int, c_void_pp]),
+    "pt_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pt_comm_rank": (C.c_int, [C.c_void_p]),
+    "pt_comm_world": (C.c_int, [C.c_void_p]),
+    "pt_pass_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
+    "pt_pass_allreduce_all": (C.c_int, [c_void_pp, c_void_pp, C.c_int, C.c_uint32, C.c_int]),
     "pt_host_build_mesh_bvh": (C.c_int, [C.c_void_p, i32p, C.c_int32, C.c_int32, C.c_void_p, f32p, i32p, i32p]),
     "pt_host_check_traversal_layout": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                  C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),

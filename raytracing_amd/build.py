@@ -27,6 +27,7 @@ HOST_SOURCES = [
 ]
 DEVICE_SOURCES = [
     "capi_device.hip",
+    "capi_comm.hip",
     "device/trace_kernels.hip",
     "device/path_kernels.hip",
     "device/post_kernels.hip",
@@ -93,8 +94,26 @@ def build(force=False, verbose=True, variant=None, defines=()):
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(lib):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-lpthread"])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-lpthread", "-ldl"])
     return lib
+
+
+def kernel_sources_digest():
+    """sha256 over the sources that decide what the traversal and shading kernels execute and what
+    they read: the device directory and the host re-layout.  Counter summaries under profiles/ carry
+    the digest of the tree they were measured on; bench.py refuses to quote one whose digest differs."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for sub in ("device",):
+        for f in sorted(os.listdir(os.path.join(CSRC, sub))):
+            if f.endswith((".h", ".hip", ".inc")):
+                files.append(os.path.join(CSRC, sub, f))
+    files += [os.path.join(CSRC, "host", "accel_layout.cpp"), os.path.join(CSRC, "host", "accel_layout.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def build_facade_demo(verbose=True):

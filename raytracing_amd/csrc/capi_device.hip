@@ -5,7 +5,7 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
-#include "capi_common.h"
+#include "capi_internal.h"
 #include "device/kernels.h"
 #include "device/trace_fast.h"
 #include "host/accel_layout.h"
@@ -13,62 +13,6 @@
 #include "host/scene_types.h"
 
 using namespace rta;
-
-#define HIP_TRY(expr)                                                                                         \
-    do {                                                                                                      \
-        hipError_t _e = (expr);                                                                               \
-        if(_e != hipSuccess) return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
-    } while(0)
-
-struct pt_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int num_cus = 0;
-    void *scratch = nullptr;  // this device's copy of the file-scope scratch array (pt_pass_intersect_noalloc)
-    uint64_t next_handle = 1;
-    std::unordered_map<uint64_t, pt_tex *> textures;
-    // Draws run on streams of their own (pt_pass::lanes).  Each leaves its completion event
-    // here; everything issued on `stream` first makes `stream` wait for them (ctx_join).
-    std::vector<hipEvent_t> pending;
-    // live passes: a buffer or texture that is released is unbound from them first, so that a
-    // later draw reports the missing binding instead of reading freed memory
-    std::vector<pt_pass *> passes;
-};
-
-// Orders the context's main stream behind every draw issued so far.
-static int ctx_join(pt_ctx *ctx) {
-    for(hipEvent_t e : ctx->pending) {
-        hipError_t r = hipStreamWaitEvent(ctx->stream, e, 0);
-        if(r != hipSuccess) return fail(PT_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(r));
-    }
-    ctx->pending.clear();
-    return PT_OK;
-}
-#define JOIN_TRY(ctx)                       \
-    do {                                    \
-        int _rc = ctx_join(ctx);            \
-        if(_rc) return _rc;                 \
-    } while(0)
-
-// Reports (once) a traversal-stack overflow of any pass of the context; to be called where the
-// device has just been waited for.
-static int ctx_check_overflow(pt_ctx *ctx);
-
-struct pt_buf {
-    pt_ctx *ctx = nullptr;
-    void *dptr = nullptr;
-    size_t bytes = 0;
-    std::vector<uint8_t> shadow;  // last bytes uploaded from the host, if shadow_valid
-    bool shadow_valid = false;
-    uint64_t version = 0;  // bumped by every content change
-};
-
-struct pt_tex {
-    pt_ctx *ctx = nullptr;
-    void *dptr = nullptr;
-    int width = 0, height = 0, channels = 0, format = 0;
-    uint64_t handle = 0;
-};
 
 namespace {
 
@@ -129,6 +73,11 @@ struct pt_pass {
     pt_ctx *ctx = nullptr;
     int W = 0, H = 0;
     pt_buf *outputs[7] = {};
+    // The outputs are views into two allocations, so that the multi-GPU combine moves each group
+    // with one collective: the three accumulated ones (direct, indirect, albedo: 9 floats per
+    // pixel) are summed over the ranks, the four last-write ones (motion, depth, normal,
+    // instance index: 7 floats per pixel) are taken from the rank that drew the last sample.
+    void *d_accum_group = nullptr, *d_lastwrite_group = nullptr;
     pt_buf *slots[7] = {};
     uint64_t seen_version[7] = {};
     const pt_buf *seen_ptr[7] = {};
@@ -186,7 +135,7 @@ struct pt_pass {
     pt_profile prof;
 };
 
-static int ctx_check_overflow(pt_ctx *ctx) {
+int ctx_check_overflow(pt_ctx *ctx) {
     bool hit = false;
     for(pt_pass *p : ctx->passes)
         if(p->h_err && *static_cast<volatile unsigned *>(p->h_err)) {
@@ -552,6 +501,20 @@ int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow) {
 
 }  // namespace
 
+// For the multi-GPU combine (capi_comm.hip): the two output groups of a pass.  Marks the outputs as changed.
+int pass_output_groups(pt_pass *pass, pt_ctx **ctx, float **accum, float **lastwrite, size_t *npix) {
+    if(!pass) return fail(PT_ERR_INVALID, "null pass");
+    *ctx = pass->ctx;
+    *accum = static_cast<float *>(pass->d_accum_group);
+    *lastwrite = static_cast<float *>(pass->d_lastwrite_group);
+    *npix = (size_t)pass->W * pass->H;
+    for(int k = 0; k < 7; k++) {
+        pass->outputs[k]->version++;
+        pass->outputs[k]->shadow_valid = false;
+    }
+    return PT_OK;
+}
+
 extern "C" {
 
 // ------------------------------------------------------------------------------- context
@@ -640,6 +603,7 @@ int pt_buf_create(pt_ctx *ctx, size_t bytes, const void *host, pt_buf **out) {
 
 int pt_buf_release(pt_buf *buf) {
     if(!buf) return PT_OK;
+    if(!buf->owned) return fail(PT_ERR_INVALID, "pt_buf_release: this buffer is an output of a pass (a borrowed handle); pt_pass_destroy frees it");
     (void)hipSetDevice(buf->ctx->device);
     (void)ctx_join(buf->ctx);
     (void)hipStreamSynchronize(buf->ctx->stream);
@@ -769,7 +733,33 @@ int pt_pass_create(pt_ctx *ctx, int screen_w, int screen_h, pt_pass **out) {
     memset(&p->prof, 0, sizeof p->prof);
     const size_t npix = (size_t)screen_w * screen_h;
     int rc = PT_OK;
-    for(int k = 0; k < 7 && !rc; k++) rc = pt_buf_create(ctx, npix * OUT_CHANNELS[k] * sizeof(float), nullptr, &p->outputs[k]);
+    {
+        // order inside the groups: [direct | indirect | albedo], [motion | depth | normal | instance index]
+        hipError_t e = hipMalloc(&p->d_accum_group, npix * 9 * sizeof(float));
+        if(e == hipSuccess) e = hipMalloc(&p->d_lastwrite_group, npix * 7 * sizeof(float));
+        if(e != hipSuccess) rc = fail(PT_ERR_HIP, std::string("hipMalloc (outputs): ") + hipGetErrorString(e));
+        const int accum_order[3] = {5, 6, 0}, last_order[4] = {1, 2, 3, 4};  // indices into OUT_SLOTS
+        size_t off = 0;
+        for(int j = 0; j < 3 && !rc; j++) {
+            const int k = accum_order[j];
+            pt_buf *b = new pt_buf;
+            b->ctx = ctx; b->owned = false;
+            b->dptr = static_cast<float *>(p->d_accum_group) + off;
+            b->bytes = npix * OUT_CHANNELS[k] * sizeof(float);
+            off += npix * OUT_CHANNELS[k];
+            p->outputs[k] = b;
+        }
+        off = 0;
+        for(int j = 0; j < 4 && !rc; j++) {
+            const int k = last_order[j];
+            pt_buf *b = new pt_buf;
+            b->ctx = ctx; b->owned = false;
+            b->dptr = static_cast<float *>(p->d_lastwrite_group) + off;
+            b->bytes = npix * OUT_CHANNELS[k] * sizeof(float);
+            off += npix * OUT_CHANNELS[k];
+            p->outputs[k] = b;
+        }
+    }
     // 6 blocks of 256 threads per CU: 24 KiB of LDS stack each, 24 waves per CU
     p->trace_blocks = ctx->num_cus * 8;
     set_draw_grid(p);
@@ -813,7 +803,13 @@ int pt_pass_destroy(pt_pass *p) {
     (void)hipSetDevice(p->ctx->device);
     (void)ctx_join(p->ctx);
     (void)hipStreamSynchronize(p->ctx->stream);
-    for(int k = 0; k < 7; k++) pt_buf_release(p->outputs[k]);
+    for(int k = 0; k < 7; k++)
+        if(p->outputs[k]) {
+            unbind_everywhere(p->ctx, p->outputs[k], nullptr);
+            delete p->outputs[k];
+        }
+    if(p->d_accum_group) (void)hipFree(p->d_accum_group);
+    if(p->d_lastwrite_group) (void)hipFree(p->d_lastwrite_group);
     collect_profile(p);
     for(hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
     for(pt_pass::Lane &l : p->lanes) release_lane(l);

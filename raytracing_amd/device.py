@@ -274,6 +274,36 @@ class PathTracingPass:
             self.h = None
 
 
+class Comm:
+    """pt_comm: this rank's end of the RCCL communicator the frame is combined over (one rank per GPU)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        """bytes to hand to every rank (rank 0 makes them)."""
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        check(lib.pt_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, unique_id, rank, world):
+        assert len(unique_id) == Comm.ID_BYTES
+        h = C.c_void_p()
+        check(lib.pt_comm_create(ctx.h, C.c_char_p(unique_id), int(rank), int(world), C.byref(h)))
+        self.h = h
+        self.rank, self.world = rank, world
+
+    def allreduce(self, pass_, total_spp, last_rank):
+        """pt_pass_allreduce: sums of the accumulated outputs over the ranks / total_spp, last-write
+        outputs from last_rank; queued behind the draws, does not wait."""
+        check(lib.pt_pass_allreduce(pass_.h, self.h, int(total_spp), int(last_rank)))
+
+    def destroy(self):
+        if self.h:
+            lib.pt_comm_destroy(self.h)
+            self.h = None
+
+
 def trace_rays(pass_, rays):
     """Convenience: closest hits (HIT_DTYPE array) for host rays (n, 6)."""
     rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)

@@ -10,8 +10,10 @@ nine accumulated floats per pixel and a division by SPP finish the frame.  The f
 last-write outputs (motion, depth, normal, instanceIndex) are taken from the rank that
 rendered the last sample, which is what a single GPU would have left in them.
 
-The functions here take the collective backend as arguments so that the same logic runs
-over RCCL on GPUs and over gloo on CPUs (tests).
+On GPUs the combine is the library's own (pt_pass_allreduce over RCCL, device.Comm): the pass
+keeps each group of outputs in one allocation, so it is one all-reduce and one broadcast with no
+staging copy.  combine() below is the same arithmetic over torch.distributed, used where RCCL
+cannot run: gloo on CPUs (tests) and rehearsals of several ranks on one GPU.
 """
 import numpy as np
 
@@ -69,3 +71,26 @@ def allreduce_outputs(torch, dist, pass_, npix, total_spp, dev_tensor, via_cpu=F
         tensors[name] = dev_tensor(torch, pass_.outputs[name].device_ptr, npix * c)
     combine(dist, tensors, total_spp, world, torch, via_cpu=via_cpu)
     torch.cuda.synchronize()
+
+
+def make_comm(dist, ctx, rank, world):
+    """device.Comm for this rank: rank 0 draws the RCCL unique id, torch.distributed (whatever
+    backend the process group has) carries it to the others."""
+    from . import device
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = device.Comm.unique_id()
+        except Exception as e:  # the others must not wait for an id that will not come
+            box[0] = "pt_comm_unique_id failed: %s" % e
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    if not isinstance(box[0], bytes):
+        raise RuntimeError(box[0])
+    return device.Comm(ctx, box[0], rank, world)
+
+
+def allreduce_outputs_capi(comm, pass_, total_spp):
+    """The C-ABI form: both collectives and the 1 / SPP scaling are queued by the library on the
+    context's stream behind the draws; synchronise the context to wait for the frame."""
+    comm.allreduce(pass_, total_spp, owner_of_last_sample(total_spp, comm.world))

@@ -31,14 +31,31 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common[:1], "6", *common[2:], "--dump", one],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", *common, "--dump", two],
+    # (no launcher: bench.py --gpus 2 starts its two ranks itself)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", *common, "--dump", two],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     import json
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["steps"] == 3
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    # strong scaling: the same 6 samples, now as --steps 6 cut over the two ranks
+    three = str(tmp_path / "three.npz")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--scaling", "strong",
+                        *common[:1], "6", *common[2:], "--dump", three], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out3 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out3["scaling"] == "strong" and out3["config"]["total_spp"] == 6
+    c = np.load(three)
+    b2 = np.load(two)
+    for name in b2.files:
+        assert np.array_equal(b2[name].view(np.uint32), c[name].view(np.uint32)), name
+    # a world size that does not match --gpus is an error, not a silent single-GPU run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
     a, b = np.load(one), np.load(two)
     for name in ("motion", "depth", "normal", "instanceIndex"):
         assert np.array_equal(a[name].view(np.uint32), b[name].view(np.uint32)), name
@@ -47,3 +64,45 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
         both_nan = np.isnan(x) & np.isnan(y)
         err = np.abs(x - y) / np.maximum(np.maximum(np.abs(x), np.abs(y)), 1e-3)
         assert np.all((err < 1e-5) | both_nan), (name, float(np.nanmax(err)))
+
+
+def test_capi_allreduce_world_of_one(gpu_ctx, casa, small_sky):
+    """pt_comm_* / pt_pass_allreduce over RCCL with the one GPU of the test box as a world of one
+    rank: sums of 4 samples / 4 must equal the running mean of the same samples up to fp32
+    summation order, and the last-write outputs are untouched.  (More than one rank per GPU is
+    refused by RCCL, so N > 1 runs only where there are N GPUs: bench.py --gpus N.)"""
+    from raytracing_amd import device, multigpu, scene
+    w, h, spp = 256, 144, 4
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    jit = scene.mt19937_jitters(spp)
+
+    def frame(accum_mode):
+        for s in range(1, spp + 1):
+            p.set_params(scene.make_params(w, h, scene.casa_camera(), small_sky, spp=s, max_depth=3, jitter=jit[s - 1],
+                                           accum_mode=accum_mode))
+            p.draw()
+
+    frame(0)
+    mean = p.download()
+    for name in multigpu.ACCUMULATED:
+        p.outputs[name].fill(0.0)
+    frame(1)
+    comm = device.Comm(gpu_ctx, device.Comm.unique_id(), 0, 1)
+    multigpu.allreduce_outputs_capi(comm, p, spp)        # queued behind the draws, no wait in between
+    got = p.download()
+    for name in multigpu.LAST_WRITE:
+        assert np.array_equal(mean[name].view(np.uint32), got[name].view(np.uint32)), name
+    for name in multigpu.ACCUMULATED:
+        x, y = mean[name].astype(np.float64), got[name].astype(np.float64)
+        err = np.abs(x - y) / np.maximum(np.maximum(np.abs(x), np.abs(y)), 1e-3)
+        assert np.all((err < 1e-5) | (np.isnan(x) & np.isnan(y))), (name, float(np.nanmax(err)))
+    from raytracing_amd import _capi
+    with pytest.raises(_capi.PtError):
+        comm.allreduce(p, 0, 0)
+    with pytest.raises(_capi.PtError):
+        comm.allreduce(p, spp, 1)
+    comm.destroy()
+    p.destroy()
+    sb.release()

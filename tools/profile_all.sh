@@ -3,6 +3,7 @@
 # Results under gpurun_out/prof_<tag>/ ; copy the *_kernel_stats.csv and *.json into profiles/.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}  # (the HIP runtime starts before bench.py under rocprofv3)
 run() {  # tag, bench args...
   tag=$1; shift
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py "$@" > gpurun_out/prof_$tag.json 2> gpurun_out/prof_$tag.err || { echo "$tag failed"; tail -5 gpurun_out/prof_$tag.err; exit 1; }

@@ -38,4 +38,9 @@ if jout:
         if "FETCH_SIZE" in tot[k] and "WRITE_SIZE" in tot[k]:
             out[k]["hbm_bytes_per_launch"] = (tot[k]["FETCH_SIZE"] / calls[k]["FETCH_SIZE"] +
                                               tot[k]["WRITE_SIZE"] / calls[k]["WRITE_SIZE"]) * 1024.0
+    # which tree the counters were measured on (bench.py compares it with the tree it runs from)
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from raytracing_amd.build import kernel_sources_digest
+    out["_meta"] = {"kernel_sources_sha256": kernel_sources_digest()}
     json.dump(out, open(jout, "w"), indent=1, sort_keys=True)
