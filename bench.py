@@ -25,13 +25,6 @@ import time
 
 import numpy as np
 
-# More hardware queues than HIP's default of 4, so that more draws can overlap on the device
-# (read once, when the HIP runtime starts: before torch is imported).
-# A value the caller set is respected (and reported); under rocprofv3 the runtime has started
-# before this line runs, so the profiling scripts export the variable themselves.
-if not os.environ.get("GPU_MAX_HW_QUEUES", "").strip():
-    os.environ["GPU_MAX_HW_QUEUES"] = "16"
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -55,6 +48,10 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=6, help="draws in flight on the device (pt_pass_set_pipeline)")
     ap.add_argument("--wide-nodes", type=int, default=-1, choices=[-1, 0, 1],
                     help="node format of the ordered traversal (pt_pass_set_wide_nodes): -1 library default, 0 fp32, 1 quantised")
+    ap.add_argument("--hw-queues", type=int, default=16,
+                    help="GPU_MAX_HW_QUEUES for this process (HIP's default of 4 holds 3 draws in flight + the main stream; "
+                         "the default pipeline of 6 needs more); 0 leaves the environment as it is.  Read once, when the HIP "
+                         "runtime starts, so under rocprofv3 export the variable instead.  Reported in config.")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank draws --steps samples (N x steps in all); strong = --steps samples in all, "
                          "sliced over the ranks (BASELINE config 4: a fixed 256-spp frame cut over 2/4/8 GPUs)")
@@ -79,6 +76,8 @@ def dev_tensor(torch, ptr, n_floats):
 
 def main():
     args = parse()
+    if args.hw_queues > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)   # before torch / the HIP runtime start
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

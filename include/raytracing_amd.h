@@ -383,6 +383,52 @@ int64_t pt_host_rgbe_encode(const float *rgb, int32_t w, int32_t h, void *out, s
 /* Skybox::load_to_gpu's CPU half, src/texture/Skybox.cpp:12-53 */
 int pt_host_sky_cache(const float *rgb, int32_t w, int32_t h, float *cache_out, double *light_sum_out);
 
+/* ---- glTF binary (.glb) scenes -------------------------------------------------------------
+ * The arrays AssimpLoader::load_model (src/tool/loader.cpp:137-158) hands to the reference's
+ * scene classes, read straight from the file (the importer library is not part of this
+ * build):  one mesh per glTF mesh, triangles in index order as 96-byte records, positions /
+ * normals / uvs as stored (processMesh, loader.cpp:75-104; no TEXCOORD_0 -> zeros);  every
+ * material a RoughConductor with albedo = baseColorFactor, roughness = max(0.001,
+ * roughnessFactor), metallic = 1 (processMaterial, loader.cpp:44-73), one texture per material
+ * that names a baseColorTexture;  instances = nodes that carry a mesh, in hierarchy pre-order
+ * with accumulated local-to-world matrices, the root node's own transform reset to identity
+ * (processNode + loader.cpp:152-156; order of ResourceManager::update_globalinstance_recursive,
+ * src/ResourceManager.cpp:47-77).  What the importer would do beyond that (generated normals,
+ * quaternion node rotations, several primitives per mesh, several root nodes) is refused with
+ * PT_ERR_INVALID and a message.  No GPU. */
+typedef struct pt_glb pt_glb;
+typedef struct pt_glb_info {
+    int32_t n_meshes, n_materials, n_textures, n_instances;
+    int64_t n_triangles;
+} pt_glb_info;
+typedef struct pt_glb_material {
+    float albedo[3];
+    float roughness, metallic;
+    int32_t texture; /* index for pt_host_glb_texture, -1 = none */
+} pt_glb_material;
+int pt_host_glb_open(const char *path, pt_glb **out);
+int pt_host_glb_open_memory(const void *bytes, size_t n, pt_glb **out);
+int pt_host_glb_close(pt_glb *glb);
+int pt_host_glb_info(const pt_glb *glb, pt_glb_info *out);
+/* tri_count_out: n_meshes counts; triangles_out: n_triangles 96-byte records, meshes back to
+ * back (the layout pt_host_build_mesh_bvh takes).  Either may be NULL. */
+int pt_host_glb_meshes(const pt_glb *glb, int32_t *tri_count_out, void *triangles_out);
+int pt_host_glb_materials(const pt_glb *glb, pt_glb_material *out);
+/* The ENCODED image (JPEG, PNG ...) of texture `index`, as embedded in the file; the pointer
+ * stays valid until pt_host_glb_close.  Decoding is the host's (the reference uses stb_image,
+ * loader.cpp:23-27, rows top to bottom, not flipped).  image_index_out: the glTF image. */
+int pt_host_glb_texture(const pt_glb *glb, int32_t index, const void **bytes_out, size_t *n_out, int32_t *image_index_out);
+/* Per instance: mesh index, material index (-1 = none) and local-to-world matrix (16 floats),
+ * multiplied from the left by root_l2w when that is given (the transform the application puts
+ * on the loaded root, main.cpp:382).  Outputs may be NULL. */
+int pt_host_glb_instances(const pt_glb *glb, const float root_l2w[16], int32_t *mesh_index_out, int32_t *material_index_out,
+                          float *l2w_out);
+/* The material float stream with one record per INSTANCE (ResourceManager::reload_instances,
+ * src/ResourceManager.cpp:146-165; RoughConductor::insert_buffer, src/material/
+ * RoughConductor.cpp:26-38) and each instance's materialPtr.  Returns the number of floats
+ * (call with stream_out NULL first), negative on error. */
+int64_t pt_host_glb_material_stream(const pt_glb *glb, float *stream_out, size_t cap_floats, int32_t *material_ptr_out);
+
 /* The host half of save_as_image: quantise + flip `data` (height rows of width*channel floats,
  * bottom row first) into `pixels_out` (height*width*channel bytes, top row first), and write
  * top-row-first bytes as a PNG. */

@@ -52,6 +52,15 @@ class PtStats(C.Structure):
     ]
 
 
+class PtGlbInfo(C.Structure):
+    _fields_ = [("n_meshes", C.c_int32), ("n_materials", C.c_int32), ("n_textures", C.c_int32), ("n_instances", C.c_int32),
+                ("n_triangles", C.c_int64)]
+
+
+class PtGlbMaterial(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("roughness", C.c_float), ("metallic", C.c_float), ("texture", C.c_int32)]
+
+
 class PtProfile(C.Structure):
     _fields_ = [("extend_ms", C.c_double), ("shadow_ms", C.c_double), ("shade_ms", C.c_double),
                 ("other_ms", C.c_double), ("intersect_ms", C.c_double),
@@ -112,6 +121,15 @@ SIGNATURES = {
     "pt_comm_world": (C.c_int, [C.c_void_p]),
     "pt_pass_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
     "pt_pass_allreduce_all": (C.c_int, [c_void_pp, c_void_pp, C.c_int, C.c_uint32, C.c_int]),
+    "pt_host_glb_open": (C.c_int, [C.c_char_p, c_void_pp]),
+    "pt_host_glb_open_memory": (C.c_int, [C.c_void_p, C.c_size_t, c_void_pp]),
+    "pt_host_glb_close": (C.c_int, [C.c_void_p]),
+    "pt_host_glb_info": (C.c_int, [C.c_void_p, C.POINTER(PtGlbInfo)]),
+    "pt_host_glb_meshes": (C.c_int, [C.c_void_p, i32p, C.c_void_p]),
+    "pt_host_glb_materials": (C.c_int, [C.c_void_p, C.POINTER(PtGlbMaterial)]),
+    "pt_host_glb_texture": (C.c_int, [C.c_void_p, C.c_int32, c_void_pp, C.POINTER(C.c_size_t), i32p]),
+    "pt_host_glb_instances": (C.c_int, [C.c_void_p, f32p, i32p, i32p, f32p]),
+    "pt_host_glb_material_stream": (C.c_int64, [C.c_void_p, f32p, C.c_size_t, i32p]),
     "pt_host_build_mesh_bvh": (C.c_int, [C.c_void_p, i32p, C.c_int32, C.c_int32, C.c_void_p, f32p, i32p, i32p]),
     "pt_host_check_traversal_layout": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                  C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),

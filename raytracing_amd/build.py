@@ -24,6 +24,7 @@ HOST_SOURCES = [
     "host/sky_host.cpp",
     "host/accel_layout.cpp",
     "host/png_writer.cpp",
+    "host/glb_loader.cpp",
 ]
 DEVICE_SOURCES = [
     "capi_device.hip",
@@ -98,6 +99,15 @@ def build(force=False, verbose=True, variant=None, defines=()):
     return lib
 
 
+def build_all(verbose=True):
+    """The library, its small-stack twin (three stack entries per ray in LDS; tests/test_gpu_errors.py
+    uses it to make rays run out of stack) and the C++ demo of the facade."""
+    lib = build(verbose=verbose)
+    build(variant="smallstack", defines=["-DRT_CORE_LDS_STACK=3", "-DRT_FAST_LDS_STACK=3"], verbose=False)
+    build_facade_demo(verbose=verbose)
+    return lib
+
+
 def kernel_sources_digest():
     """sha256 over the sources that decide what the traversal and shading kernels execute and what
     they read: the device directory and the host re-layout.  Counter summaries under profiles/ carry
@@ -136,6 +146,7 @@ def build_facade_demo(verbose=True):
 if __name__ == "__main__":
     argv = sys.argv[1:]
     var = argv[argv.index("--variant") + 1] if "--variant" in argv else None
-    print(build(force="--force" in argv, variant=var, defines=[a for a in argv if a.startswith("-D")]))
-    if var is None:
-        print(build_facade_demo())
+    if var is None and "--force" not in argv:
+        print(build_all())
+    else:
+        print(build(force="--force" in argv, variant=var, defines=[a for a in argv if a.startswith("-D")]))

@@ -8,6 +8,8 @@
 #include "host/sky_host.h"
 #include "host/png_writer.h"
 #include "host/accel_layout.h"
+#include "host/glb_loader.h"
+#include <cstdio>
 
 namespace rta {
 static thread_local std::string g_last_error;
@@ -187,6 +189,116 @@ int pt_host_write_png(const char *path, int32_t width, int32_t height, int32_t c
     std::string err;
     if(!rta::write_png(path, width, height, channel, pixels, err)) return fail(PT_ERR_INVALID, err);
     return PT_OK;
+}
+
+// ---- glTF binary scenes: the arrays AssimpLoader::load_model would hand to the scene classes ----
+struct pt_glb {
+    GlbScene scene;
+};
+
+int pt_host_glb_open_memory(const void *bytes, size_t n, pt_glb **out) {
+    if(!bytes || !out) return fail(PT_ERR_INVALID, "pt_host_glb_open_memory: null argument");
+    pt_glb *g = new pt_glb;
+    std::string err;
+    if(!load_glb(static_cast<const uint8_t *>(bytes), n, g->scene, err)) {
+        delete g;
+        return fail(PT_ERR_INVALID, err);
+    }
+    *out = g;
+    return PT_OK;
+}
+
+int pt_host_glb_open(const char *path, pt_glb **out) {
+    if(!path || !out) return fail(PT_ERR_INVALID, "pt_host_glb_open: null argument");
+    FILE *f = fopen(path, "rb");
+    if(!f) return fail(PT_ERR_INVALID, std::string("pt_host_glb_open: cannot read ") + path);
+    std::vector<uint8_t> data;
+    uint8_t buf[1 << 16];
+    size_t got;
+    while((got = fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + got);
+    fclose(f);
+    return pt_host_glb_open_memory(data.data(), data.size(), out);
+}
+
+int pt_host_glb_close(pt_glb *glb) {
+    delete glb;
+    return PT_OK;
+}
+
+int pt_host_glb_info(const pt_glb *glb, pt_glb_info *out) {
+    if(!glb || !out) return fail(PT_ERR_INVALID, "pt_host_glb_info: null argument");
+    out->n_meshes = (int32_t)glb->scene.tri_count.size();
+    out->n_materials = (int32_t)glb->scene.materials.size();
+    out->n_textures = (int32_t)glb->scene.textures.size();
+    out->n_instances = (int32_t)glb->scene.instances.size();
+    out->n_triangles = (int64_t)glb->scene.triangles.size();
+    return PT_OK;
+}
+
+int pt_host_glb_meshes(const pt_glb *glb, int32_t *tri_count_out, void *triangles_out) {
+    if(!glb) return fail(PT_ERR_INVALID, "pt_host_glb_meshes: null argument");
+    const GlbScene &s = glb->scene;
+    if(tri_count_out) memcpy(tri_count_out, s.tri_count.data(), s.tri_count.size() * sizeof(int32_t));
+    if(triangles_out) memcpy(triangles_out, s.triangles.data(), s.triangles.size() * sizeof(TriangleRec));
+    return PT_OK;
+}
+
+int pt_host_glb_materials(const pt_glb *glb, pt_glb_material *out) {
+    if(!glb || !out) return fail(PT_ERR_INVALID, "pt_host_glb_materials: null argument");
+    static_assert(sizeof(pt_glb_material) == sizeof(GlbMaterial), "material records must match");
+    memcpy(out, glb->scene.materials.data(), glb->scene.materials.size() * sizeof(GlbMaterial));
+    return PT_OK;
+}
+
+int pt_host_glb_texture(const pt_glb *glb, int32_t index, const void **bytes_out, size_t *n_out, int32_t *image_index_out) {
+    if(!glb || !bytes_out || !n_out) return fail(PT_ERR_INVALID, "pt_host_glb_texture: null argument");
+    if(index < 0 || (size_t)index >= glb->scene.textures.size()) return fail(PT_ERR_INVALID, "pt_host_glb_texture: index out of range");
+    const GlbTexture &t = glb->scene.textures[index];
+    *bytes_out = glb->scene.file.data() + t.offset;
+    *n_out = t.bytes;
+    if(image_index_out) *image_index_out = t.image;
+    return PT_OK;
+}
+
+int pt_host_glb_instances(const pt_glb *glb, const float root_l2w[16], int32_t *mesh_index_out, int32_t *material_index_out,
+                          float *l2w_out) {
+    if(!glb) return fail(PT_ERR_INVALID, "pt_host_glb_instances: null argument");
+    Mat4 root = Mat4::identity();
+    if(root_l2w) memcpy(root.data(), root_l2w, 64);
+    const GlbScene &s = glb->scene;
+    for(size_t i = 0; i < s.instances.size(); i++) {
+        if(mesh_index_out) mesh_index_out[i] = s.instances[i].mesh;
+        if(material_index_out) material_index_out[i] = s.instances[i].material;
+        if(l2w_out) {
+            const Mat4 m = root_l2w ? mul(root, s.instances[i].l2w) : s.instances[i].l2w;
+            memcpy(l2w_out + i * 16, m.data(), 64);
+        }
+    }
+    return PT_OK;
+}
+
+int64_t pt_host_glb_material_stream(const pt_glb *glb, float *stream_out, size_t cap_floats, int32_t *material_ptr_out) {
+    if(!glb) return fail(PT_ERR_INVALID, "pt_host_glb_material_stream: null argument");
+    const GlbScene &s = glb->scene;
+    std::vector<float> stream;
+    for(size_t i = 0; i < s.instances.size(); i++) {
+        const int m = s.instances[i].material;
+        int ptr;
+        if(m >= 0) {
+            const GlbMaterial &gm = s.materials[m];
+            ptr = material_append_conductor(stream, gm.albedo, gm.roughness, gm.metallic, gm.texture);
+        } else {
+            // an instance without a material keeps the class defaults (src/material/RoughConductor.h)
+            const float white[3] = {1.0f, 1.0f, 1.0f};
+            ptr = material_append_conductor(stream, white, 1.0f, 0.0f, -1);
+        }
+        if(material_ptr_out) material_ptr_out[i] = ptr;
+    }
+    if(stream_out) {
+        if(cap_floats < stream.size()) return fail(PT_ERR_INVALID, "pt_host_glb_material_stream: output holds fewer floats than the stream");
+        memcpy(stream_out, stream.data(), stream.size() * sizeof(float));
+    }
+    return (int64_t)stream.size();
 }
 
 }  // extern "C"

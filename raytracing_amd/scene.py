@@ -602,3 +602,43 @@ def mt19937_jitters(n_spp, static_blender=False):
             x = y = np.float32(0.5)
         out.append((float(x), float(y)))
     return out
+
+
+def load_glb_capi(path, root_l2w=None):
+    """The same scene description as load_glb, read by the library's own reader (pt_host_glb_*):
+    dict with tri_count, triangles (n, 24), materials (list of dicts), texture_bytes (encoded
+    images), instances (mesh, material, l2w), material stream + pointers."""
+    g = C.c_void_p()
+    check(lib.pt_host_glb_open(str(path).encode(), C.byref(g)))
+    try:
+        info = _capi.PtGlbInfo()
+        check(lib.pt_host_glb_info(g, C.byref(info)))
+        tri_count = np.zeros(info.n_meshes, np.int32)
+        tris = np.zeros((info.n_triangles, 24), np.float32)
+        check(lib.pt_host_glb_meshes(g, _i32p(tri_count), tris.ctypes.data))
+        mats = (_capi.PtGlbMaterial * max(info.n_materials, 1))()
+        if info.n_materials:
+            check(lib.pt_host_glb_materials(g, mats))
+        materials = [dict(type=1, albedo=tuple(np.float32(x) for x in mats[k].albedo), roughness=np.float32(mats[k].roughness),
+                          metallic=np.float32(mats[k].metallic), tex=int(mats[k].texture)) for k in range(info.n_materials)]
+        tex_bytes, tex_image = [], []
+        for k in range(info.n_textures):
+            ptr, n, img = C.c_void_p(), C.c_size_t(), C.c_int32()
+            check(lib.pt_host_glb_texture(g, k, C.byref(ptr), C.byref(n), C.byref(img)))
+            tex_bytes.append(C.string_at(ptr, n.value))
+            tex_image.append(img.value)
+        mesh_index = np.zeros(info.n_instances, np.int32)
+        material_index = np.zeros(info.n_instances, np.int32)
+        l2w = np.zeros((info.n_instances, 16), np.float32)
+        root = None if root_l2w is None else _f32p(np.ascontiguousarray(root_l2w, np.float32))
+        check(lib.pt_host_glb_instances(g, root, _i32p(mesh_index), _i32p(material_index), _f32p(l2w)))
+        n = int(lib.pt_host_glb_material_stream(g, None, 0, None))
+        check(n)
+        stream = np.zeros(n, np.float32)
+        material_ptr = np.zeros(info.n_instances, np.int32)
+        check(int(lib.pt_host_glb_material_stream(g, _f32p(stream), n, _i32p(material_ptr))))
+        return dict(tri_count=tri_count, triangles=tris, materials=materials, texture_bytes=tex_bytes, texture_image=tex_image,
+                    mesh_index=mesh_index, material_index=material_index, l2w=l2w, material_stream=stream,
+                    material_ptr=material_ptr)
+    finally:
+        lib.pt_host_glb_close(g)

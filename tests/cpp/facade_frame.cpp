@@ -2,7 +2,11 @@
 // (main.cpp:169-315, without the raster pass and the denoisers): per spp use() / bind_texture /
 // uniforms / draw(), then merge -> static blend -> tone mapping -> save_as_image.
 // Input: a directory of raw arrays written by tests/test_gpu_facade.py; output: the raw output
-// buffers and frame.png in the same directory.  Usage: facade_frame <dir>
+// buffers and frame.png in the same directory.  Usage: facade_frame <dir> [scene.glb]
+// With a .glb the program builds the scene buffers itself, the way init_scene() does
+// (main.cpp:376-391: load_model, root rotation (-90, 0, 0), reload_scene), through the library's
+// host helpers; only the decoded texture pixels, the sky and the frame parameters still come
+// from the directory.
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -55,8 +59,52 @@ int main(int argc, char **argv) {
         pt_tex *skyTex = create_texture_f32(sky_w, sky_h, 3, reinterpret_cast<const float *>(sky.data()));
         pt_tex *cacheTex = create_texture_f32(sky_w, sky_h, 3, reinterpret_cast<const float *>(cache.data()));
 
-        auto tris = slurp(dir + "tris.bin"), inst = slurp(dir + "inst.bin"), mesh = slurp(dir + "mesh_nodes.bin");
-        auto scene = slurp(dir + "scene_nodes.bin"), mats = slurp(dir + "materials.bin"), lights = slurp(dir + "lights.bin");
+        std::vector<char> tris, inst, mesh, scene, mats, lights;
+        if(argc >= 3) {
+            auto need = [](int rc) {
+                if(rc < 0) throw std::runtime_error(pt_last_error());
+            };
+            pt_glb *glb = nullptr;
+            need(pt_host_glb_open(argv[2], &glb));                                   // AssimpLoader::load_model, main.cpp:381
+            pt_glb_info gi;
+            need(pt_host_glb_info(glb, &gi));
+            std::vector<int32_t> tri_count(gi.n_meshes), mesh_index(gi.n_instances), material_ptr(gi.n_instances);
+            tris.resize((size_t)gi.n_triangles * sizeof(TriangleRecord));
+            need(pt_host_glb_meshes(glb, tri_count.data(), tris.data()));
+            // o1->transform.rotation = vec3(-90, 0, 0) under an identity scene root (main.cpp:382, Instance::matrix_to_global)
+            const float zero[3] = {0, 0, 0}, one[3] = {1, 1, 1}, rot[3] = {-90, 0, 0};
+            float scene_m[16], o1[16], root[16];
+            need(pt_host_transform_matrix(zero, zero, one, scene_m));
+            need(pt_host_transform_matrix(zero, rot, one, o1));
+            need(pt_host_mat4_mul(scene_m, o1, root));
+            std::vector<float> l2w((size_t)gi.n_instances * 16);
+            need(pt_host_glb_instances(glb, root, mesh_index.data(), nullptr, l2w.data()));
+            const int64_t n_mat = pt_host_glb_material_stream(glb, nullptr, 0, nullptr);
+            need((int)n_mat);
+            mats.resize((size_t)n_mat * sizeof(float));
+            need((int)pt_host_glb_material_stream(glb, reinterpret_cast<float *>(mats.data()), (size_t)n_mat, material_ptr.data()));
+            // Mesh::build_meshBVH + reload_meshes, then reload_scene (ResourceManager.cpp:95-224)
+            size_t n_nodes = 0;
+            for(int32_t c : tri_count) n_nodes += 2 * (size_t)c - 1;
+            mesh.resize(n_nodes * sizeof(BVHNodeInfo));
+            std::vector<float> root_box((size_t)gi.n_meshes * 6);
+            std::vector<int32_t> siz(gi.n_meshes), depth(gi.n_meshes);
+            need(pt_host_build_mesh_bvh(tris.data(), tri_count.data(), gi.n_meshes, 0, mesh.data(), root_box.data(), siz.data(), depth.data()));
+            inst.resize((size_t)gi.n_instances * sizeof(InstanceInfo));
+            scene.resize((2 * (size_t)gi.n_instances - 1) * sizeof(BVHNodeInfo));
+            int32_t stats[2];
+            need(pt_host_build_scene(root_box.data(), siz.data(), depth.data(), gi.n_meshes, l2w.data(), mesh_index.data(), material_ptr.data(),
+                                     gi.n_instances, inst.data(), scene.data(), stats));
+            need(pt_host_glb_close(glb));
+            std::cout << "glb_scene " << gi.n_triangles << " triangles, " << gi.n_instances << " instances, BVH size " << stats[0]
+                      << " depth " << stats[1] << std::endl;   // what main.cpp:393-395 prints
+            dump(dir + "glb_tris.bin", tris); dump(dir + "glb_inst.bin", inst); dump(dir + "glb_mesh_nodes.bin", mesh);
+            dump(dir + "glb_scene_nodes.bin", scene); dump(dir + "glb_materials.bin", mats);
+        } else {
+            tris = slurp(dir + "tris.bin"); inst = slurp(dir + "inst.bin"); mesh = slurp(dir + "mesh_nodes.bin");
+            scene = slurp(dir + "scene_nodes.bin"); mats = slurp(dir + "materials.bin");
+        }
+        lights = slurp(dir + "lights.bin");
         // the reassignment pattern of ResourceManager.cpp:53-54: x.release(); x = SSBOBuffer<T>(n, data);
         rm.textureHandleSSBO.release();
         rm.textureHandleSSBO = SSBOBuffer<uint64_t>((uint)handles.size(), handles.data());

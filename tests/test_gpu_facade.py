@@ -21,7 +21,8 @@ def bit_equal(a, b):
     return a.size == b.size and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
 
 
-def test_facade_frame_loop(casa, small_sky, oracle_mod, tmp_path):
+@pytest.mark.parametrize("from_glb", [False, True])
+def test_facade_frame_loop(casa, small_sky, oracle_mod, tmp_path, from_glb):
     from raytracing_amd import scene
     assert os.path.exists(EXE), "tests/cpp/facade_frame is built by __graft_entry__.build() / raytracing_amd.build.build_facade_demo()"
     w, h, spp_n, depth = 112, 63, 3, 3
@@ -44,8 +45,19 @@ def test_facade_frame_loop(casa, small_sky, oracle_mod, tmp_path):
                               light_count=len(casa.lights)) for s in range(1, spp_n + 1)]
     open(d + "/params.bin", "wb").write(b"".join(bytes(p) for p in prms))
 
-    r = subprocess.run([EXE, d], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stdout + r.stderr
+    if from_glb:
+        # the program loads casa_obj.glb and builds every scene buffer itself (pt_host_glb_*, pt_host_build_*)
+        for f in ("tris", "inst", "mesh_nodes", "scene_nodes", "materials"):
+            os.remove(d + "/%s.bin" % f)
+        r = subprocess.run([EXE, d, os.path.join(ROOT, "assets", "casa_obj.glb")], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "glb_scene 34689 triangles, 19 instances" in r.stdout
+        for f, a in (("tris", casa.triangles), ("inst", casa.instances), ("mesh_nodes", casa.mesh_nodes), ("scene_nodes", casa.scene_nodes),
+                     ("materials", np.ascontiguousarray(casa.materials, np.float32))):
+            assert open(d + "/glb_%s.bin" % f, "rb").read() == a.tobytes(), f
+    else:
+        r = subprocess.run([EXE, d], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
     assert "ssbo_ok" in r.stdout
 
     osc = oracle_mod.OracleScene(casa, small_sky)
