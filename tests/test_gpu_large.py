@@ -1,0 +1,83 @@
+"""The large configurations on a real device: a 2 M-triangle scene with rough dielectrics, RGBA8
+albedo maps and MAX_DEPTH 16 against the oracle bit for bit (the shape of BASELINE config 5), and a
+10 M-triangle scene at 3840x2160, MAX_DEPTH 8 (BASELINE config 4's frame) through the property that
+needs no oracle run at that size: the ordered traversal and the reference-order traversal, two
+independent kernels over two node formats, must produce the same seven images.  Both also check
+that no ray ran out of traversal stack (spill depth is sized from these deeper trees) and that
+buffers beyond 2^30 bytes are addressed correctly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bit_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_2m_triangles_dielectrics_textures_depth16_vs_oracle(gpu_ctx, small_sky, oracle_mod):
+    from raytracing_amd import device, scene
+    sd = scene.synthetic_scene(2_000_000, dielectric_fraction=0.5, textures=4, texture_size=1024)
+    assert len(sd.triangles) > 1_900_000 and len(sd.instances) == 64 and len(sd.textures) == 4
+    assert (np.round(sd.materials[sd.material_ptr]) == 2).sum() >= 20          # rough dielectrics among the 64 instances
+    w, h, depth, spp = 320, 180, 16, 2
+    sb = device.SceneBuffers(gpu_ctx, sd, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    osc = oracle_mod.OracleScene(sd, small_sky)
+    jit = scene.mt19937_jitters(spp)
+    ref = None
+    for s in range(1, spp + 1):
+        prm = scene.make_params(w, h, scene.synthetic_camera(), small_sky, spp=s, jitter=jit[s - 1], max_depth=depth)
+        p.set_params(prm)
+        p.draw()
+        ref, cnt = osc.render(prm, ref)
+    got = p.download()          # (raises if a ray ran out of stack)
+    for k in ref:
+        assert _bit_equal(got[k], ref[k]), k
+    st = p.stats()
+    assert st["reference_order_forced"] == 0 and st["samples"] == w * h * spp
+    assert st["rays_extend"] + st["rays_shadow"] > 4 * w * h * spp              # several bounces per path on average (open scene)
+    assert (got["instanceIndex"] >= 0).mean() > 0.5
+    p.destroy()
+    sb.release()
+
+
+def test_10m_triangles_4k_depth8_ordered_equals_reference_order(gpu_ctx, small_sky, oracle_mod):
+    from raytracing_amd import device, scene
+    sd = scene.synthetic_scene(10_000_000)
+    assert len(sd.triangles) > 9_900_000
+    assert sd.triangles.nbytes + sd.mesh_nodes.nbytes > (1 << 30)               # offsets beyond 32-bit byte counts are in play
+    w, h, depth = 3840, 2160, 8
+    sb = device.SceneBuffers(gpu_ctx, sd, small_sky)
+    prm = scene.make_params(w, h, scene.synthetic_camera(), small_sky, spp=1, max_depth=depth)
+    images = []
+    stats = []
+    for mode in (0, 1):
+        p = device.PathTracingPass(gpu_ctx, w, h)
+        p.bind_scene(sb)
+        p.set_traversal(mode)
+        p.set_params(prm)
+        p.draw()
+        images.append(p.download())     # (raises if a ray ran out of stack)
+        stats.append(p.stats())
+        p.destroy()
+    for k in images[0]:
+        assert np.array_equal(images[0][k].view(np.uint32), images[1][k].view(np.uint32)), k
+    assert stats[0]["samples"] == w * h and stats[0]["rays_extend"] == stats[1]["rays_extend"]
+    assert stats[0]["rays_shadow"] == stats[1]["rays_shadow"] and stats[0]["rays_extend"] > 2 * w * h
+    assert stats[0]["rays_retraced"] < 1e-3 * stats[0]["rays_extend"] and stats[1]["rays_retraced"] == 0
+    # a window the oracle finishes in seconds, same scene and depth, bit for bit
+    sw, sh = 480, 270
+    p = device.PathTracingPass(gpu_ctx, sw, sh)
+    p.bind_scene(sb)
+    prm = scene.make_params(sw, sh, scene.synthetic_camera(), small_sky, spp=1, max_depth=depth)
+    p.set_params(prm)
+    p.draw()
+    got = p.download()
+    ref, _ = oracle_mod.OracleScene(sd, small_sky).render(prm)
+    for k in ref:
+        assert _bit_equal(got[k], ref[k]), k
+    p.destroy()
+    sb.release()
