@@ -254,17 +254,30 @@ def main():
         prof = dominant = None
         if not args.no_profile:
             p.set_pipeline(1)
-            p.set_profiling(True)
-            p.profile(reset=True)
             n_prof = min(len(my_samples), 16)
+            # (a) what a caller that issues one draw and then consumes it gets: draws one at a time, as shipped
+            #     (the thin tail of each draw in one launch), no events around the launches
+            for s in list(my_samples)[:2]:
+                draw(s, accum_mode)
+            ctx.synchronize()
             t1 = time.perf_counter()
             for s in list(my_samples)[:n_prof]:
                 draw(s, accum_mode)
-            ctx.synchronize()
+                ctx.synchronize()
             serial_ms = (time.perf_counter() - t1) / n_prof * 1e3
+            # (b) per-kernel times of the vertex-by-vertex chain (tail launch off, so that every ray of the
+            #     draws is traced by the kernels that are timed)
+            p.set_tail_threshold(0)
+            p.set_profiling(True)
+            p.profile(reset=True)
+            p.stats(reset=True)
+            for s in list(my_samples)[:n_prof]:
+                draw(s, accum_mode)
+            ctx.synchronize()
             prof = p.profile()
             pst = p.stats(reset=True)
             p.set_profiling(False)
+            p.set_tail_threshold(-1)
             p.set_pipeline(args.pipeline)
             note("per-kernel profiling pass done")
             prof["draws"] = n_prof
@@ -275,6 +288,7 @@ def main():
                         prof["extend_ms"] + prof["trace_ms"] + prof["shadow_ms"],
                         prof["extend_launches"] + prof["trace_launches"] + prof["shadow_launches"],
                         pst["rays_extend"] + pst["rays_shadow"])
+
 
     # max time over ranks, sum of units over ranks
     if world > 1:
@@ -445,7 +459,7 @@ def main():
                                       "below 0.3 the kernel is bound by vector-ALU issue and latency (valu_issue_busy, "
                                       "lanes_active_per_valu_inst of 64), not by HBM.")
             if prof:
-                out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "trace_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms")}
+                out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "trace_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms", "tail_ms")}
                 if "draws" in prof:
                     out["kernel_ms"]["over_draws"] = prof["draws"]
                     out["kernel_ms"]["one_draw_in_flight_ms_per_step"] = prof["serial_ms_per_step"]

@@ -218,6 +218,15 @@ int pt_pass_set_wide_nodes(pt_pass *pass, int format);
  * per-kernel times of overlapping draws include each other: profile with 1. */
 int pt_pass_set_pipeline(pt_pass *pass, int draws_in_flight);
 
+/* The thin tail of a draw; no counterpart in the reference, results do not depend on it.  Late
+ * path vertices carry few paths, yet each costs a chain of launches that wait for their slowest
+ * ray.  From the first vertex at which fewer than `threshold` paths were alive in the last
+ * finished draw (the pass reads that draw's queue lengths without waiting), ONE launch carries
+ * the remaining paths through all their remaining vertices.  threshold 0 turns it off; -1
+ * (default) is the library's choice.  Used with the ordered traversal and the sky as the only
+ * light; other draws run vertex by vertex throughout. */
+int pt_pass_set_tail_threshold(pt_pass *pass, int threshold);
+
 /* Per-kernel device time, measured with HIP events recorded on the launching stream around
  * every launch while profiling is enabled.  No counterpart in the reference (its only
  * timing is an FPS counter, main.cpp:423-435); used by bench.py for the roofline figure. */
@@ -228,6 +237,9 @@ typedef struct pt_profile {
     double trace_ms;         /* launches that trace the shadow rays of one vertex together with the
                                 extend rays of the next (ordered traversal, no analytic lights)     */
     uint64_t trace_launches;
+    double tail_ms;          /* the launch that carries the few paths still alive at a late vertex
+                                through all their remaining vertices (shading and tracing)           */
+    uint64_t tail_launches;
 } pt_profile;
 int pt_pass_set_profiling(pt_pass *pass, int enable);
 /* Waits for the stream, then reports the time accumulated since the last reset. */

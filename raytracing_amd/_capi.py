@@ -66,7 +66,8 @@ class PtProfile(C.Structure):
                 ("other_ms", C.c_double), ("intersect_ms", C.c_double),
                 ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64), ("shade_launches", C.c_uint64),
                 ("other_launches", C.c_uint64), ("intersect_launches", C.c_uint64),
-                ("trace_ms", C.c_double), ("trace_launches", C.c_uint64)]
+                ("trace_ms", C.c_double), ("trace_launches", C.c_uint64),
+                ("tail_ms", C.c_double), ("tail_launches", C.c_uint64)]
 
 
 # name -> (restype, argtypes); also the list the symbol-export test walks
@@ -99,6 +100,7 @@ SIGNATURES = {
     "pt_pass_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_wide_nodes": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_pass_set_tail_threshold": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_post_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_post_static_blend": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_post_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -31,6 +31,7 @@ DEVICE_SOURCES = [
     "capi_comm.hip",
     "device/trace_kernels.hip",
     "device/path_kernels.hip",
+    "device/tail_kernels.hip",
     "device/post_kernels.hip",
     "device/denoise_kernels.hip",
 ]

@@ -51,6 +51,21 @@ struct DrawParams {
     int redo_counter_base;  // index in `counters` of the per-vertex re-trace counts, -1 when there are none
     // per-draw queue counters, zeroed before generate: [d] = paths alive at vertex d
     unsigned *counters;
+    // Where finalize leaves a copy of the queue lengths for the host (pinned host memory as the
+    // device sees it; see QueueSnapshot), or null.
+    unsigned *snapshot;
+    int tail_from;  // vertex from which the tail launch took over (MAX_DEPTH + 1: it did not run)
+};
+
+// Queue lengths of the last finished draw, written by its finalize launch into pinned host memory:
+// the host reads them (without waiting for anything) to decide from which vertex the next draw
+// hands its paths to the tail launch.  seq_begin is written first and seq_end last, so a reader
+// that finds them equal has a consistent copy.  Only a heuristic reads this: outputs do not depend on it.
+struct QueueSnapshot {
+    unsigned seq_begin;
+    unsigned max_depth, tail_from, npix;
+    unsigned alive[66];  // [d] = paths alive at vertex d, valid for d <= min(tail_from, max_depth)
+    unsigned seq_end;
 };
 
 struct FastScene;
@@ -80,6 +95,12 @@ void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, cons
                             const unsigned *queue_s, const unsigned *count_s, const PathRay *rays, PathHit *hits,
                             ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo, unsigned *redo_count,
                             const PathThroughput *thr, PathAccum *acc, unsigned long long *shadow_rays_stat);
+// One launch for every vertex from dep0 on: each wave carries its paths through shade / trace /
+// shade ... to their ends (tail_kernels.hip).  queue_in / count_in: the paths alive at vertex dep0,
+// with their hits in place; next_batch: a zeroed counter.
+void launch_path_tail(hipStream_t s, const FastScene &fsc, const TraceScene &tsc, const DrawParams &dp, int dep0, int blocks,
+                      const unsigned *queue_in, const unsigned *count_in, unsigned *next_batch);
+int tail_paths_per_block();
 void launch_generate(hipStream_t s, const DrawParams &dp);
 // shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to
 // queue_out and paths with pending light samples to shadow_queue.

@@ -69,8 +69,43 @@ __device__ __forceinline__ unsigned wang_hash(unsigned seed) {
     return seed;
 }
 
+// The sampler's value for dimension d and index i is the XOR of the direction numbers V[d][j]
+// over the set bits j of i (S/basic/sobol.glsl:6-14).  XOR is associative, so the same value
+// comes out of eight table reads, one per 4-bit digit of i, from a table that holds the XOR of
+// every subset of four consecutive direction numbers: T[d][k][v] = XOR of V[d][4k + b] over the
+// bits b of v.  No loop over the bits, no divergence between lanes with different indices.
+constexpr int SOBOL_DIMS = 20;
+constexpr int SOBOL_NIBBLE_WORDS = SOBOL_DIMS * 8 * 16;  // 2 560 words = 10 KiB
+struct SobolNibbleTable {
+    unsigned t[SOBOL_NIBBLE_WORDS];
+};
+constexpr SobolNibbleTable make_sobol_nibble_table() {
+    constexpr unsigned V[SOBOL_DIMS * 32] = {
+#include "sobol_table.inc"
+    };
+    SobolNibbleTable r{};
+    for(int d = 0; d < SOBOL_DIMS; d++)
+        for(int k = 0; k < 8; k++)
+            for(int v = 0; v < 16; v++) {
+                unsigned x = 0;
+                for(int b = 0; b < 4; b++)
+                    if((v >> b) & 1) x ^= V[d * 32 + 4 * k + b];
+                r.t[(d * 8 + k) * 16 + v] = x;
+            }
+    return r;
+}
+static __device__ const SobolNibbleTable g_sobol_nibbles = make_sobol_nibble_table();
+
+// every thread of the block calls this once, before the first rand()
+__device__ __forceinline__ void load_sobol_to_lds(unsigned *s_T) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(g_sobol_nibbles.t);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_T);
+    for(int k = threadIdx.x; k < SOBOL_NIBBLE_WORDS / 4; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+}
+
 struct Sampler {
-    const unsigned *V;  // 640-entry direction table (in LDS)
+    const unsigned *T;  // the nibble table (in LDS)
     unsigned seed, dim;
     // Dimensions 0..19 are the reference's.  Dimension d >= 20 (which the reference reads
     // out of bounds) reuses table row 1 + (d-1) % 19 with the index replaced by
@@ -82,13 +117,10 @@ struct Sampler {
             d = 1u + (d - 1u) % 19u;
             i = wang_hash(i + 0x9E3779B9u * fold);
         }
-        unsigned r = 0;
-        const unsigned *row = V + d * 32u;
-        while(i != 0u) {
-            int j = __ffs((int)i) - 1;
-            r ^= row[j];
-            i &= i - 1u;
-        }
+        const unsigned *row = T + d * 128u;
+        const unsigned r = (row[i & 15u] ^ row[16u + ((i >> 4) & 15u)]) ^ (row[32u + ((i >> 8) & 15u)] ^ row[48u + ((i >> 12) & 15u)]) ^
+                           (row[64u + ((i >> 16) & 15u)] ^ row[80u + ((i >> 20) & 15u)]) ^
+                           (row[96u + ((i >> 24) & 15u)] ^ row[112u + (i >> 28)]);
         return (float)r * 2.3283064365386963e-10f;  // 1.0 / float(0xFFFFFFFFu) = 2^-32
     }
 };

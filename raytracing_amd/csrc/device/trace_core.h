@@ -66,16 +66,21 @@ __device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float
 // counter per batch instead of one per lane-refill.  A single counter word sustains only
 // ~88 returning atomics per microsecond chip-wide; drawing single indices made that the
 // bottleneck of every trace launch (16 Mi rays / ~24 lanes per refill = 0.7 M atomics = 8 ms).
-struct WaveRayFeed {
+// MIN_BATCH: the smallest batch.  64 fills a wave at once; the second-pass launches, which carry
+// a few dozen long rays, use 4 so that those spread over many waves (a wave steps through all
+// kinds of node its lanes hold, one after the other: the fewer rays share a wave, the sooner
+// each is done).
+template <unsigned MIN_BATCH>
+struct WaveRayFeedT {
     unsigned base = 0, left = 0;  // wave-uniform: next index of the current batch, indices left in it
     bool dry = false;             // wave-uniform: the counter has passed n_rays
     unsigned batch;
-    __device__ explicit WaveRayFeed(unsigned n_rays) {
+    __device__ explicit WaveRayFeedT(unsigned n_rays) {
         // enough batches for every wave of the launch to get several; at least one ray per lane
         const unsigned waves = gridDim.x * (blockDim.x / 64u);
         unsigned b = n_rays / (waves * 4u + 1u);
-        b = b < 64u ? 64u : (b > 1024u ? 1024u : b);
-        batch = b & ~63u;
+        b = b < MIN_BATCH ? MIN_BATCH : (b > 1024u ? 1024u : b);
+        batch = b >= 64u ? (b & ~63u) : b;
     }
     // Every lane of the wave must call this together.  Returns true and sets idx for lanes
     // that asked for a ray and got one; lanes that asked but got none ask again next time.
@@ -101,6 +106,31 @@ struct WaveRayFeed {
     }
 };
 
+using WaveRayFeed = WaveRayFeedT<64u>;
+using SparseRayFeed = WaveRayFeedT<4u>;
+
+// The same interface over a set of rays that belongs to the calling wave alone (indices
+// 0 .. n_rays-1, no counter in memory): for kernels in which a wave traces the rays of its own
+// paths between two shading steps.
+struct LocalRayFeed {
+    unsigned base = 0, left;
+    bool dry;
+    __device__ explicit LocalRayFeed(unsigned n_rays) : left(n_rays), dry(n_rays == 0u) {}
+    __device__ bool take(bool want, unsigned *, unsigned, unsigned &idx) {
+        const unsigned long long m = __ballot(want);
+        if(m == 0ull) return false;
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const bool got = want && rank < left;
+        idx = base + rank;
+        const unsigned asked = (unsigned)__popcll(m);
+        const unsigned taken = asked < left ? asked : left;
+        base += taken;
+        left -= taken;
+        dry = left == 0u;
+        return got;
+    }
+};
+
 // A ray with a NaN in its origin or direction cannot hit anything (every triangle test
 // compares NaN and fails), but NaN-dropping min/max let it pass every box: it would visit the
 // whole scene to report a miss.  Such rays (the reference's refract() makes them) are
@@ -117,7 +147,7 @@ __device__ __forceinline__ bool ray_has_nan(const float o[3], const float d[3]) 
 //
 // Source: bool load(unsigned idx, float o[3], float d[3], bool &any_hit)   false = no ray for idx
 // Sink:   void store(unsigned idx, const LaneHit &h)                        h.tri < 0 = miss
-template <class Source, class Sink>
+template <class Feed = WaveRayFeed, class Source, class Sink>
 __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &src, Sink &sink, unsigned *next_ray,
                                                  unsigned n_rays, uint2 *s_stack) {
     constexpr int REFILL_BELOW = 44;
@@ -126,7 +156,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
 
     bool active = false, have = false, exhausted = false, any_hit = false;
-    WaveRayFeed feed(n_rays);
+    Feed feed(n_rays);
     unsigned ray_idx = 0;
     int sp = 0;
     float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;  // world-space ray

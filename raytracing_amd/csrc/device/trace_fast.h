@@ -100,7 +100,7 @@ __device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float
 // Source: bool load(unsigned idx, float o[3], float d[3], bool &any_hit)
 // Sink:   void store(unsigned idx, const LaneHit &h, bool ambiguous)
 // QUANT: the wide nodes are QNodes (64 bytes, decoded on the fly) instead of WNodes.
-template <bool QUANT, class Source, class Sink>
+template <bool QUANT, class Feed = WaveRayFeed, class Source, class Sink>
 __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, Sink &sink, unsigned *next_ray,
                                               unsigned n_rays, uint2 *s_stack) {
 #ifndef RT_FAST_REFILL
@@ -122,7 +122,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
 
     bool active = false, have = false, exhausted = false, any_hit = false;
-    WaveRayFeed feed(n_rays);
+    Feed feed(n_rays);
     unsigned ray_idx = 0;
     int sp = 0;
     float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;  // world ray

@@ -3,6 +3,7 @@
 // (trace_core.h, exact by construction) and an ordered form (trace_fast.h) that hands the
 // rays it cannot decide (near-ties in t) to the reference-order form through a redo queue.
 #include "kernels.h"
+#include "path_state_io.h"
 #include "trace_fast.h"
 
 namespace rta {
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void intersect_kernel(TraceScene sc, c
     if(redo && blockIdx.x == 0 && threadIdx.x == 0 && *redo_count) atomicAdd(retraced_stat, (unsigned long long)*redo_count);
     RaySource src{rays, redo, hits};
     HitSink sink{hits, redo};
-    trace_persistent(sc, src, sink, next_counter, redo ? *redo_count : n, s_stack);
+    if(redo) trace_persistent<SparseRayFeed>(sc, src, sink, next_counter, *redo_count, s_stack);
+    else trace_persistent(sc, src, sink, next_counter, n, s_stack);
 }
 
 template <bool QUANT>
@@ -87,19 +89,11 @@ struct ExtendSource {
     __device__ float bound(unsigned idx) const { return provisional ? provisional[queue ? queue[idx] : idx].t : RT_INF; }
     __device__ bool load(unsigned idx, float o[3], float d[3], bool &any_hit) const {
         const unsigned px = queue ? queue[idx] : idx;
-        const float4 *p = reinterpret_cast<const float4 *>(rays + px);
-        const float4 a = p[0], b = p[1];
-        o[0] = a.x; o[1] = a.y; o[2] = a.z;
-        d[0] = b.x; d[1] = b.y; d[2] = b.z;
+        load_path_ray(rays, px, o, d);
         any_hit = false;
         return true;
     }
 };
-__device__ __forceinline__ void write_path_hit(PathHit *hits, unsigned px, const LaneHit &h) {
-    float4 *p = reinterpret_cast<float4 *>(hits + px);
-    p[0] = make_float4(h.t, h.u, h.v, __int_as_float(h.tri));
-    p[1] = make_float4(__int_as_float(h.inst), 0.0f, 0.0f, 0.0f);
-}
 struct ExtendSink {
     const unsigned *queue;
     PathHit *hits;
@@ -123,7 +117,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void extend_kernel(TraceScene sc, cons
     __shared__ uint2 s_stack[LDS_STACK * TRACE_BLOCK];
     ExtendSource src{queue, rays, second_pass ? hits : nullptr};
     ExtendSink sink{queue, hits};
-    trace_persistent(sc, src, sink, next_counter, *count, s_stack);
+    if(second_pass) trace_persistent<SparseRayFeed>(sc, src, sink, next_counter, *count, s_stack);
+    else trace_persistent(sc, src, sink, next_counter, *count, s_stack);
 }
 
 template <bool QUANT>
@@ -221,20 +216,7 @@ struct ShadowApplySink {
     const PathThroughput *thr;
     PathAccum *acc;
     __device__ void store(unsigned idx, const LaneHit &h) const {
-        const unsigned px = queue[idx];
-        const float4 *e = reinterpret_cast<const float4 *>(shadow + px);
-        const float4 e0 = e[0], e1 = e[1];
-        if(!(h.tri < 0 || h.t * h.t > e0.w)) return;  // occluded
-        const float4 t0 = *reinterpret_cast<const float4 *>(thr + px);
-        PathAccum *a = acc + px;
-        a->gi[0] = a->gi[0] + t0.x * e1.x;
-        a->gi[1] = a->gi[1] + t0.y * e1.y;
-        a->gi[2] = a->gi[2] + t0.z * e1.z;
-        if(__float_as_uint(e1.w) & 2u) {
-            a->di[0] = e1.x;
-            a->di[1] = e1.y;
-            a->di[2] = e1.z;
-        }
+        apply_sky_sample(shadow, thr, acc, queue[idx], h);
     }
 };
 struct PathSink {

@@ -254,6 +254,10 @@ class PathTracingPass:
         """How many draws may overlap on the device (1..16); outputs do not depend on it."""
         check(lib.pt_pass_set_pipeline(self.h, int(draws_in_flight)))
 
+    def set_tail_threshold(self, threshold):
+        """Paths alive below which one launch finishes the draw (0 = never, -1 = the library's choice)."""
+        check(lib.pt_pass_set_tail_threshold(self.h, int(threshold)))
+
     def set_profiling(self, enable=True):
         check(lib.pt_pass_set_profiling(self.h, int(enable)))
 
