@@ -36,6 +36,14 @@ DEVICE_SOURCES = [
     "device/denoise_kernels.hip",
 ]
 
+# Per-source flags.  The traversal kernels lose to the SLP vectoriser: it pairs scalar fp32 operations into
+# v_pk_* instructions and pays for each pair with register moves (measured on MI355X: 16 Mi random rays
+# against casa 8.2 -> 9.1 Grays/s without it; path tracing unchanged).
+import json as _json
+EXTRA = _json.loads(os.environ.get("RTA_EXTRA_FLAGS", "null")) or {
+    "device/trace_kernels.hip": ["-fno-slp-vectorize"],
+}
+
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result"]
 
 
@@ -79,7 +87,7 @@ def build(force=False, verbose=True, variant=None, defines=()):
         objs.append(obj)
         if force or _newer(src, obj, hdrs):
             if rel.endswith(".hip"):
-                cmd = [hipcc, "--offload-arch=gfx950", *common, "-c", src, "-o", obj]
+                cmd = [hipcc, "--offload-arch=gfx950", *common, *EXTRA.get(rel, []), "-c", src, "-o", obj]
             else:
                 cmd = [hipcc, "-x", "c++", *common, "-c", src, "-o", obj]
             jobs.append(cmd)
@@ -150,4 +158,4 @@ if __name__ == "__main__":
     if var is None and "--force" not in argv:
         print(build_all())
     else:
-        print(build(force="--force" in argv, variant=var, defines=[a for a in argv if a.startswith("-D")]))
+        print(build(force="--force" in argv, variant=var, defines=[a for a in argv if a.startswith("-") and a not in ("--variant", "--force")]))

@@ -224,10 +224,22 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
             const bool is_leaf = have && kind == REF_TRIANGLE, is_inst = have && kind == REF_INSTANCE;
             const bool is_inner = have && !is_leaf && !is_inst;
             const int n_inner = __popcll(__ballot(is_inner));
+#ifdef RT_PICK_ONE
+            // one kind of entry per step: the one that most lanes hold (weighted), so that a step runs one
+            // body at the best lane count on offer instead of up to three at whatever each finds
+            const int n_leaf = __popcll(__ballot(is_leaf)), n_inst = __popcll(__ballot(is_inst));
+            const int s_in = n_inner * RT_W_INNER, s_lf = n_leaf * RT_W_LEAF, s_is = n_inst * RT_W_INST;
+            const bool serve_inner = s_in >= s_lf && s_in >= s_is;
+            const bool serve_leaf = !serve_inner && s_lf >= s_is;
+            const bool serve_inst = !serve_inner && !serve_leaf;
+            const bool go = (is_inner && serve_inner) || (is_leaf && serve_leaf) || (is_inst && serve_inst);
+#else
+            const bool serve_inner = true;
             const bool starving = n_inner < SERVE_ALL_BELOW;
             const bool serve_leaf = starving || __popcll(__ballot(is_leaf)) >= LEAF_BATCH;
             const bool serve_inst = starving || __popcll(__ballot(is_inst)) >= INST_BATCH;
             const bool go = is_inner || (is_leaf && serve_leaf) || (is_inst && serve_inst);
+#endif
 #ifdef RT_TRACE_STATS
             st_slots += 1;
             {
@@ -272,7 +284,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                     *sc.error_flag = 1u;
                 }
             };
-            if(is_inner) {
+            if(serve_inner && is_inner) {
                 // one wide node: up to four child boxes; the nearest child next, the others
                 // deferred so that they come back nearest first.  Entry distances are >= 0, so
                 // their bit patterns order like the numbers and 0xFFFFFFFF marks "not taken".
