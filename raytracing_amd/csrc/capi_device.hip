@@ -996,7 +996,9 @@ int pt_pass_draw(pt_pass *p) {
     const bool ordered = use_ordered(p);
     unsigned *qr = static_cast<unsigned *>(L.queue_r.p);
     HIP_TRY(hipMemsetAsync(cnt, 0, CNT_TOTAL * 4, s));
-    {
+    // camera rays: a launch of their own, unless the ordered extend of vertex 0 makes them where it traces them
+    const bool fused_primary = ordered && !raster_first;
+    if(!fused_primary) {
         ScopedTimer t(p, K_OTHER);
         launch_generate(s, dp);
     }
@@ -1014,8 +1016,11 @@ int pt_pass_draw(pt_pass *p) {
     auto extend = [&](int dep, const unsigned *q) {
         ScopedTimer t(p, K_EXTEND);
         if(ordered) {
-            launch_extend_fast(s, fsc, grid, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, qr,
-                               cnt + CNT_REDO + dep);
+            if(dep == 0 && fused_primary)
+                launch_primary_fast(s, fsc, grid, dp, cnt + CNT_NEXT + 2 * dep, qr, cnt + CNT_REDO + dep);
+            else
+                launch_extend_fast(s, fsc, grid, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, qr,
+                                   cnt + CNT_REDO + dep);
             // near-ties in t: decided by the reference-order traversal
             launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep, true);
         } else {

@@ -102,6 +102,9 @@ void launch_path_tail(hipStream_t s, const FastScene &fsc, const TraceScene &tsc
                       const unsigned *queue_in, const unsigned *count_in, unsigned *next_batch);
 int tail_paths_per_block();
 void launch_generate(hipStream_t s, const DrawParams &dp);
+// generate + the ordered extend of vertex 0 in one launch (camera rays made where they are traced)
+void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter, unsigned *redo,
+                         unsigned *redo_count);
 // shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to
 // queue_out and paths with pending light samples to shadow_queue.
 void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,

@@ -4,6 +4,7 @@
 // rays it cannot decide (near-ties in t) to the reference-order form through a redo queue.
 #include "kernels.h"
 #include "path_state_io.h"
+#include "shade_vertex.h"
 #include "trace_fast.h"
 
 namespace rta {
@@ -132,6 +133,49 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_fast_kernel(Fas
     trace_ordered<QUANT>(sc, src, sink, next_counter, *count, s_stack);
 }
 
+// ---- primary rays: generate + extend(0) in one launch --------------------------------------------
+// The lane that is handed slot i makes that pixel's camera ray (shader/pathtracing.glsl:595-608),
+// initialises the slot's path state and traces the ray, instead of a launch of its own writing
+// all rays first and this one reading them back.
+struct PrimarySource {
+    const DrawParams &dp;
+    __device__ bool load(unsigned i, float o[3], float d[3], bool &any_hit) const {
+        unsigned px, py;
+        if(!state_pixel(dp, i, px, py)) return false;  // a slot of an edge tile that names no pixel: nobody reads it
+        V3 ro, rd;
+        camera_ray(dp.p, dp.tan_half_fov, px, py, ro, rd);
+        float4 *r = reinterpret_cast<float4 *>(dp.rays + i);
+        r[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+        r[1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+        float4 *t = reinterpret_cast<float4 *>(dp.thr + i);
+        t[0] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        t[1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(1u));  // sobolcurdim = 1, :602
+        float4 *a = reinterpret_cast<float4 *>(dp.acc + i);
+        a[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        a[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        a[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        o[0] = ro.x; o[1] = ro.y; o[2] = ro.z;
+        d[0] = rd.x; d[1] = rd.y; d[2] = rd.z;
+        any_hit = false;
+        return true;
+    }
+};
+
+template <bool QUANT>
+__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_fast_kernel(FastScene sc, DrawParams dp, unsigned *next_counter,
+                                                                  unsigned *redo, unsigned *redo_count) {
+    __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
+    if(blockIdx.x == 0 && threadIdx.x == 0) {
+        // the books generate_kernel keeps (path_kernels.hip)
+        atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H);
+        atomicAdd(&dp.stats[3], 1ull);
+        dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
+    }
+    PrimarySource src{dp};
+    ExtendSinkFast sink{nullptr, dp.hits, redo, redo_count};
+    trace_ordered<QUANT>(sc, src, sink, next_counter, (unsigned)dp.npix, s_stack);
+}
+
 // ---- shadow ------------------------------------------------------------------------------
 // Work item idx = q * n_shadow + k: light sample k of the path in slot queue[q].  The ray
 // starts at that path's current ray origin (the shaded point).  Sample 0 (sky) only needs
@@ -250,6 +294,12 @@ void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, cons
                             const PathThroughput *thr, PathAccum *acc, unsigned long long *shadow_rays_stat) {
     hipLaunchKernelGGL(sc.hdr.quantised ? path_trace_fast_kernel<true> : path_trace_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue_e, count_e, queue_s, count_s, rays,
                        hits, shadow, npix, next_counter, redo, redo_count, thr, acc, shadow_rays_stat);
+}
+
+void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter, unsigned *redo,
+                         unsigned *redo_count) {
+    hipLaunchKernelGGL(sc.hdr.quantised ? primary_fast_kernel<true> : primary_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp,
+                       next_counter, redo, redo_count);
 }
 
 void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n,
