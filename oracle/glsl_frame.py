@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE, build container only.  Runs the reference's WHOLE fragment shader
+(shader/pathtracing.glsl and everything it includes, read from /root/reference) as a C++ program,
+one main() per pixel (oracle/glsl_frame_harness.cpp, against the glm headers the reference vendors),
+on the casa demo scene, and stores its seven output buffers as tests/golden/glsl_frame_casa.npz.
+tests/test_oracle.py then checks the oracle against that frame.
+
+The shader text is never copied into the repository: the expanded translation unit goes to
+oracle/_ref/glsl_pathtracing.inc (git-ignored).  Changes made to the text, all mechanical:
+  1. `#include shader/...` lines replaced by the named file (what read_shader, src/tool/tool.cpp:42-68, does);
+  2. `#version` and `#extension` lines dropped;
+  3. `layout(...) [readonly|writeonly] buffer X { T name[]; };`  ->  `static T *name;`
+  4. `uniform T x [= v];` -> `static T x [= v];`   `const uniform` -> `static const`   `in vec2 screen_uv;` -> `static vec2 screen_uv;`
+  5. parameter qualifiers: `out T` -> `T &`, `inout T` -> `T &`, `in T` -> `T`.
+Nothing inside any function body other than rule 5's parameter lists is touched; aggregate
+constructors such as Ray(a, b) compile as they stand under -std=gnu++20.
+
+Inputs the GL application would provide: the seven scene buffers and the frame's uniforms come from
+raytracing_amd.scene (bit-identical to the compiled reference builder where that can be checked,
+tests/golden/casa_bvh.json); the four raster G-buffer images hold the primary hit the shader's own
+traversal finds (depth = t or 1e6, instance index), which is what the reference's raster pass
+produces up to rasterisation rules -- with RasterizaionFor1st off the shader uses them only for the
+depth output and the albedo lookup.
+Usage: python oracle/glsl_frame.py"""
+import os
+import re
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != HERE]   # (this directory holds a module named like the package)
+sys.path.insert(0, ROOT)
+
+
+def expand(rel, seen=()):
+    assert rel not in seen, "include cycle"
+    out = []
+    for line in open(os.path.join(REF, rel), encoding="utf-8").read().split("\n"):
+        m = re.match(r"\s*#include\s+(shader/\S+)", line)
+        out.append(expand(m.group(1), seen + (rel,)) if m else line)
+    return "\n".join(out)
+
+
+def translate(text):
+    text = re.sub(r"^\s*#(version|extension)\b.*$", "", text, flags=re.M)
+    text = re.sub(r"layout\s*\([^)]*\)\s*(?:readonly\s+|writeonly\s+)?buffer\s+\w+\s*\{\s*(\w+)\s+(\w+)\s*\[\s*\]\s*;\s*\}\s*;",
+                  r"static \1 *\2;", text)
+    text = re.sub(r"^const\s+uniform\b", "static const", text, flags=re.M)
+    text = re.sub(r"^uniform\b", "static", text, flags=re.M)
+    text = re.sub(r"^in\s+vec2\s+screen_uv\s*;", "static vec2 screen_uv;", text, flags=re.M)
+    text = re.sub(r"\b(?:out|inout)\s+(float|vec3|uint|Intersection|BSDFQueryRecord)\s+", r"\1 &", text)
+    text = re.sub(r"\bin\s+(BSDFQueryRecord|Frame|Triangle|Intersection)\s+", r"\1 ", text)
+    assert "layout" not in re.sub(r"#ifdef COMPUTE_SHADER.*?#e(lse|ndif)", "", text, flags=re.S), "a layout() declaration was not understood"
+    return text
+
+
+def build(fixed_transcendentals=False):
+    """fixed_transcendentals: the shader's sin / cos / atan / asin / pow resolve to the recipes of
+    oracle_math.h (what the oracle and the HIP path use) instead of the C library's."""
+    os.makedirs(os.path.join(HERE, "_ref"), exist_ok=True)
+    open(os.path.join(HERE, "_ref", "glsl_pathtracing.inc"), "w", encoding="utf-8").write(translate(expand("shader/pathtracing.glsl")))
+    exe = os.path.join(HERE, "_ref", "glsl_frame_harness" + ("_fixed" if fixed_transcendentals else ""))
+    cmd = ["g++", "-std=gnu++20", "-O2", "-fsingle-precision-constant", "-ffp-contract=off", "-w", "-I" + os.path.join(REF, "include"),
+           "-I" + HERE, os.path.join(HERE, "glsl_frame_harness.cpp"), "-o", exe]
+    if fixed_transcendentals:
+        cmd.append("-DGLSL_FIXED_TRANSCENDENTALS")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("the reference's shader did not compile as C++:\n" + r.stderr[-6000:])
+    return exe
+
+
+def pad16(b):
+    return b + b"\0" * (-len(b) % 16)
+
+
+def tex_blob(a, nearest=False):
+    a = np.ascontiguousarray(a)
+    h, w, c = a.shape
+    return pad16(struct.pack("<5i", w, h, c, int(a.dtype == np.float32), int(nearest))) + pad16(a.tobytes())
+
+
+def run(exe, sd, sky, prm, jitters, gbuf, workdir):
+    """gbuf: per sample (depth, normal, uv, instance) float images h x w x c, row 0 = bottom row."""
+    u = struct.pack("<5i", prm.SCREEN_W, prm.SCREEN_H, prm.WINDOW_W, prm.WINDOW_H, prm.MAX_DEPTH)
+    u += struct.pack("<4f", prm.fov, prm.cameraNear, prm.cameraFar, prm.skybox_Light_SUM)
+    u += struct.pack("<2i", prm.SKY_W, prm.SKY_H)
+    u += struct.pack("<2I", prm.frameCounter, len(jitters))
+    u += struct.pack("<5i", prm.BRDFSampling, prm.SkyboxSampling, prm.SkyboxLighting, prm.RasterizaionFor1st, prm.lightCount)
+    u += struct.pack("<16f", *prm.v2wMat) + struct.pack("<16f", *prm.backprojMat)
+    for j in jitters:
+        u += struct.pack("<2f", *j)
+    blob = pad16(u)
+    mats = np.ascontiguousarray(sd.materials, np.float32)
+    blob += struct.pack("<7Q", len(mats), len(sd.triangles), len(sd.instances), len(sd.mesh_nodes), len(sd.scene_nodes), len(sd.lights),
+                        len(sd.textures))
+    assert len(blob) % 16 == 8
+    blob = pad16(blob)  # (the harness reads the seven counts, then aligns)
+    for a in (mats, sd.triangles, sd.instances, sd.mesh_nodes, sd.scene_nodes, sd.lights):
+        blob += pad16(np.ascontiguousarray(a).tobytes())
+    for t in sd.textures:
+        blob += tex_blob(t)
+    blob += tex_blob(sky.rgb) + tex_blob(sky.cache)
+    assert len(gbuf) == len(jitters)
+    for g in gbuf:   # one set of raster images per sample (the raster pass is drawn per sample, main.cpp:174-175)
+        blob += tex_blob(g[0]) + tex_blob(g[1]) + tex_blob(g[2]) + tex_blob(g[3], nearest=True)
+    fin, fout = os.path.join(workdir, "glsl_frame_in.bin"), os.path.join(workdir, "glsl_frame_out.bin")
+    open(fin, "wb").write(blob)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("glsl_frame_harness failed (%d): %s" % (r.returncode, r.stderr[-2000:]))
+    raw = np.fromfile(fout, np.float32)
+    w, h = prm.SCREEN_W, prm.SCREEN_H
+    out, off = {}, 0
+    for name, c in (("albedo", 3), ("motion", 2), ("depth", 1), ("normal", 3), ("instanceIndex", 1), ("directLum", 3), ("indirectLum", 3)):
+        out[name] = raw[off:off + w * h * c].reshape(h, w, c).copy()
+        off += w * h * c
+    os.remove(fin)
+    os.remove(fout)
+    return out
+
+
+CASES = {
+    # tag: (scene, width, height, MAX_DEPTH, samples, switches of make_params)
+    "d2": ("casa", 128, 72, 2, 2, {}),                                    # the reference's default MaxDepth; two samples: running mean
+    "d4": ("casa", 128, 72, 4, 1, {}),                                    # every Sobol dimension the reference defines
+    "nobrdf": ("casa", 96, 54, 2, 1, dict(brdf_sampling=False)),          # the spherical_sample branch
+    "nosky": ("casa", 96, 54, 2, 1, dict(skybox_sampling=False)),         # sky light only through escaped BSDF samples
+    "nolight": ("casa", 64, 36, 2, 1, dict(skybox_lighting=False)),       # no sky light at all
+    # rough dielectrics, albedo maps, a point and a directional light (a small procedural scene).  MAX_DEPTH 3: a
+    # dielectric path draws 5 numbers per bounce, so the fourth bounce would reach Sobol dimension 20, which the
+    # reference reads out of bounds (sobol_matrix.glsl:25) -- nothing defined to compare with there
+    "synth": ("synth", 112, 63, 3, 1, {}),
+}
+
+
+def case_scene(kind):
+    from raytracing_amd import scene
+    if kind == "casa":
+        return scene.casa_scene(os.path.join(ROOT, "assets", "casa_obj.glb")), scene.casa_camera()
+    return scene.synthetic_scene(6000, dielectric_fraction=0.5, lights=2, textures=3, texture_size=32), scene.synthetic_camera()
+
+
+SKY_SIZE = (256, 128)
+
+
+def main():
+    from oracle import oracle
+    from raytracing_amd import scene
+    exes = {"libm": build(False), "fixed": build(True)}
+    sky = scene.procedural_sky(*SKY_SIZE)
+    workdir = os.path.join(HERE, "_ref")
+    out = {}
+    for tag, (kind, w, h, max_depth, spp, switches) in CASES.items():
+        sd, camera = case_scene(kind)
+        osc = oracle.OracleScene(sd, sky)
+        jit = scene.mt19937_jitters(spp)
+        gbufs = []
+        for s in range(1, spp + 1):
+            # what the raster pass would have drawn for this sample: the primary hit of every pixel (the oracle's
+            # closest hits are pinned bit for bit by the compiled reference, tests/golden/casa_rays.npz)
+            prim, _ = osc.render(scene.make_params(w, h, camera, sky, spp=1, frame=1, jitter=jit[s - 1], max_depth=0))
+            gbufs.append((prim["depth"].reshape(h, w, 1), prim["normal"].reshape(h, w, 3), np.zeros((h, w, 2), np.float32),
+                          prim["instanceIndex"].reshape(h, w, 1)))
+        prm = scene.make_params(w, h, camera, sky, spp=1, frame=1, jitter=jit[0], max_depth=max_depth, light_count=len(sd.lights), **switches)
+        for kind2, exe in exes.items():
+            res = run(exe, sd, sky, prm, jit, gbufs, workdir)
+            for k, v in res.items():
+                # with the C library's transcendentals only what they touch is kept (the rest is equal in both runs)
+                if kind2 == "fixed" or k in ("directLum", "indirectLum", "albedo"):
+                    out["%s_%s_%s" % (tag, kind2, k)] = v
+        print(tag, "done: %dx%d depth %d spp %d" % (w, h, max_depth, spp), flush=True)
+    dst = os.path.join(ROOT, "tests", "golden", "glsl_frame_casa.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -139,7 +139,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
     float tn = 0;
 
 #ifdef RT_TRACE_STATS
-    unsigned long long st_slots = 0, st_inner = 0, st_leaf = 0, st_inst = 0, st_iter = 0, st_leaf_runs = 0, st_inst_runs = 0;
+    unsigned long long st_slots = 0, st_inner = 0, st_leaf = 0, st_inst = 0, st_iter = 0, st_leaf_runs = 0, st_inst_runs = 0, st_scene = 0;
 #endif
     for(;;) {
         {
@@ -253,6 +253,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
             if(go) {
                 if(kind == REF_TRIANGLE) st_leaf++;
                 else if(kind == REF_INSTANCE) st_inst++;
+                else if(RT_TRACE_STATS == 3 && kind == REF_SCENE_INNER) st_scene++;
                 else st_inner++;
             }
 #endif
@@ -418,6 +419,10 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
         atomicAdd(dbg + 0, st_iter);
         atomicAdd(dbg + 1, st_leaf_runs);
         atomicAdd(dbg + 2, st_inst_runs);
+    } else if(RT_TRACE_STATS == 3) {  // steps by level: mesh wide nodes, scene wide nodes, instance entries
+        atomicAdd(dbg + 0, st_inner);
+        atomicAdd(dbg + 1, st_scene);
+        atomicAdd(dbg + 2, st_inst);
     } else {
         atomicAdd(dbg + 0, st_slots);
         atomicAdd(dbg + 1, st_inner + st_inst);
