@@ -57,6 +57,8 @@ def parse():
                          "sliced over the ranks (BASELINE config 4: a fixed 256-spp frame cut over 2/4/8 GPUs)")
     ap.add_argument("--collective", default="capi", choices=["capi", "torch"],
                     help="N > 1: combine through the library's own pt_pass_allreduce (RCCL, default) or through torch.distributed")
+    ap.add_argument("--material-grouping", type=int, default=-1, choices=[-1, 0, 1],
+                    help="pt_pass_set_material_grouping: -1 the library's choice (default: off), 0 off, 1 on")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank control flow on ONE GPU: all ranks use device 0, gloo backend, collectives staged through the host")
     ap.add_argument("--dump", default=None, help="rank 0 writes the final output buffers to this .npz")
@@ -144,6 +146,7 @@ def main():
     p = device.PathTracingPass(ctx, W if wl != "casa_isect" else 16, H if wl != "casa_isect" else 16)
     p.bind_scene(sb)
     p.set_wide_nodes(args.wide_nodes)
+    p.set_material_grouping(args.material_grouping)
     _r = device.Buffer(ctx, np.array([0, 0, 0, 0, 0, 1], np.float32))
     _h = device.Buffer(ctx, nbytes=device.HIT_DTYPE.itemsize)
     p.intersect(_r, 1, _h)

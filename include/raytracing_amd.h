@@ -227,6 +227,15 @@ int pt_pass_set_pipeline(pt_pass *pass, int draws_in_flight);
  * light; other draws run vertex by vertex throughout. */
 int pt_pass_set_tail_threshold(pt_pass *pass, int threshold);
 
+/* Grouping of paths by material type inside the shade launches; no counterpart in the reference
+ * (whose fragment shader dispatches per pixel, shader/materials/materials.glsl:82-111), results do
+ * not depend on it.  Every block of a shade launch first moves the paths that hit a rough
+ * dielectric behind the others, so that at most one of its four waves runs both BSDFs' code.
+ * -1 (default): the library's choice, currently off (on the 10 M-triangle scene with half the
+ * instances dielectric it measured 1 % slower: neighbouring pixels mostly hit one instance);
+ * 0: off;  1: on. */
+int pt_pass_set_material_grouping(pt_pass *pass, int mode);
+
 /* Per-kernel device time, measured with HIP events recorded on the launching stream around
  * every launch while profiling is enabled.  No counterpart in the reference (its only
  * timing is an FPS counter, main.cpp:423-435); used by bench.py for the roofline figure. */

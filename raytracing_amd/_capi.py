@@ -101,6 +101,7 @@ SIGNATURES = {
     "pt_pass_set_wide_nodes": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_tail_threshold": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_pass_set_material_grouping": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_post_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_post_static_blend": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_post_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -95,7 +95,8 @@ struct alignas(64) InstAccel {
     uint32_t root_ref;               // mesh root: inner node (a TNode) or, for a 1-triangle mesh, the triangle
     int32_t material_ptr;
     uint32_t wide_root_ref;          // the same root for the ordered traversal (a WNode or the triangle)
-    uint32_t pad0;
+    uint32_t material_type;          // the type word of its material record, rounded (1 conductor, 2 dielectric): the
+                                     // shade launch groups paths by it before it assigns them to lanes
     float root_lo[3], root_hi[3];    // box of the mesh root (tested in local space)
     float world_lo[3], world_hi[3];  // box of the instance's scene-level leaf (tested in world space)
     uint32_t pad1[4];

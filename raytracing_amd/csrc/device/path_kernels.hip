@@ -59,7 +59,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 4
 #endif
-template <bool RASTER_FIRST>
+template <bool RASTER_FIRST, bool GROUP>
 __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES, SHADE_WAVES))) void shade_kernel(DrawParams dp, int dep, const unsigned *queue_in,
                                                             const unsigned *count_in, unsigned *queue_out,
                                                             unsigned *count_out, unsigned *shadow_queue,
@@ -76,8 +76,41 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
         if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
     }
 
-    for(unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += nthreads) {
-        const unsigned i = queue_in ? queue_in[q] : q;
+    __shared__ unsigned s_slot[GROUP ? SHADE_BLOCK : 1];
+    __shared__ unsigned s_count[GROUP ? SHADE_BLOCK / 64 : 1];
+    for(unsigned q0 = blockIdx.x * blockDim.x; q0 < n; q0 += nthreads) {
+        const unsigned q = q0 + threadIdx.x;
+        unsigned i = q < n ? (queue_in ? queue_in[q] : q) : 0u;
+        bool mine = q < n;
+        if(GROUP) {
+            // Paths that hit a dielectric go to the back of the block's 256, the others stay in front, order kept
+            // within each group; which lane shades a path changes nothing about what is computed for it.
+            bool back = false;
+            if(mine) {
+                const int inst = RASTER_FIRST ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[1].x);
+                const int tri = RASTER_FIRST ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[0].w);
+                if(tri >= 0 && inst >= 0 && inst < dp.n_instances) back = dp.inst[inst].material_type == 2u;
+            }
+            const unsigned wave = threadIdx.x >> 6;
+            const unsigned long long m_back = __ballot(back), m_front = __ballot(mine && !back);
+            if((threadIdx.x & 63u) == 0u) s_count[wave] = (unsigned)__popcll(m_front) | ((unsigned)__popcll(m_back) << 16);
+            __syncthreads();
+            unsigned front_before = 0, back_before = 0, front_total = 0;
+            for(unsigned w = 0; w < SHADE_BLOCK / 64; w++) {
+                const unsigned c = s_count[w];
+                if(w < wave) { front_before += c & 0xFFFFu; back_before += c >> 16; }
+                front_total += c & 0xFFFFu;
+            }
+            const unsigned lane_lt = __builtin_amdgcn_mbcnt_hi((unsigned)((back ? m_back : m_front) >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned)(back ? m_back : m_front), 0u));
+            if(mine) s_slot[back ? front_total + back_before + lane_lt : front_before + lane_lt] = i;
+            __syncthreads();
+            const unsigned n_here = n - q0 < (unsigned)SHADE_BLOCK ? n - q0 : (unsigned)SHADE_BLOCK;
+            mine = threadIdx.x < n_here;
+            i = mine ? s_slot[threadIdx.x] : 0u;
+            __syncthreads();  // (s_slot and s_count are reused by the next round)
+        }
+        if(!mine) continue;
         bool continues, has_shadow;
         shade_vertex<RASTER_FIRST>(dp, dep, i, s_V, continues, has_shadow);
         // paths that end simply are not appended (queue compaction)
@@ -190,13 +223,14 @@ void launch_generate(hipStream_t s, const DrawParams &dp) {
 }
 
 void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,
-                  unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count) {
+                  unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group_by_material) {
+    const dim3 grid(shade_grid(dp.npix)), block(SHADE_BLOCK);
     if(dep == 0 && dp.p.RasterizaionFor1st != 0)
-        hipLaunchKernelGGL(shade_kernel<true>, dim3(shade_grid(dp.npix)), dim3(SHADE_BLOCK), 0, s, dp, dep, queue_in, count_in,
-                           queue_out, count_out, shadow_queue, shadow_count);
+        hipLaunchKernelGGL((shade_kernel<true, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
+    else if(group_by_material)
+        hipLaunchKernelGGL((shade_kernel<false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
     else
-        hipLaunchKernelGGL(shade_kernel<false>, dim3(shade_grid(dp.npix)), dim3(SHADE_BLOCK), 0, s, dp, dep, queue_in, count_in,
-                           queue_out, count_out, shadow_queue, shadow_count);
+        hipLaunchKernelGGL((shade_kernel<false, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
 }
 
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,

@@ -540,7 +540,7 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
             a.world_lo[k] = 0.0f;
             a.world_hi[k] = 0.0f;
         }
-        a.pad0 = 0;
+        a.material_type = 0;  // (filled in by the pass, which sees the material buffer)
         memset(a.pad1, 0, sizeof a.pad1);
         max_mesh_height = std::max<int>(max_mesh_height, ml.height[s.meshIndex]);
     }

@@ -258,6 +258,10 @@ class PathTracingPass:
         """Paths alive below which one launch finishes the draw (0 = never, -1 = the library's choice)."""
         check(lib.pt_pass_set_tail_threshold(self.h, int(threshold)))
 
+    def set_material_grouping(self, mode):
+        """Shade launches group paths by material type: -1 the library's choice (off), 0 never, 1 always."""
+        check(lib.pt_pass_set_material_grouping(self.h, int(mode)))
+
     def set_profiling(self, enable=True):
         check(lib.pt_pass_set_profiling(self.h, int(enable)))
 

@@ -90,3 +90,30 @@ def test_tail_really_runs(gpu_ctx, casa, small_sky):
     assert p.profile()["tail_launches"] == 0
     p.destroy()
     sb.release()
+
+
+def test_material_grouping_changes_nothing(gpu_ctx, small_sky, oracle_mod):
+    """pt_pass_set_material_grouping: the shade launches move paths that hit a dielectric behind the others
+    inside every block; the frame (checked against the oracle) and the ray counts stay the same."""
+    from raytracing_amd import device, scene
+    sd = scene.synthetic_scene(30000, dielectric_fraction=0.5, textures=3, texture_size=64, lights=1)
+    w, h, depth = 333, 187, 6          # (sizes that leave ragged blocks and tiles)
+    sb = device.SceneBuffers(gpu_ctx, sd, small_sky)
+    prm = scene.make_params(w, h, scene.synthetic_camera(), small_sky, spp=1, max_depth=depth, light_count=1)
+    ref, _ = oracle_mod.OracleScene(sd, small_sky).render(prm)
+    stats = []
+    for mode in (0, 1, -1):
+        p = device.PathTracingPass(gpu_ctx, w, h)
+        p.bind_scene(sb)
+        p.set_material_grouping(mode)
+        p.set_params(prm)
+        p.draw()
+        got = p.download()
+        for k in ref:
+            a, b = got[k], ref[k]
+            assert np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))), (k, mode)
+        st = p.stats()
+        stats.append((st["rays_extend"], st["rays_shadow"], st["rays_retraced"]))
+        p.destroy()
+    assert stats[0] == stats[1] == stats[2]
+    sb.release()
