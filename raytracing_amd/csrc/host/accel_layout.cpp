@@ -106,6 +106,9 @@ struct WideGroup {
     std::vector<int32_t> owner;   // reference node of wide node k
     std::vector<uint8_t> height;  // height of the wide subtree under wide node k
     bool ordered = true;          // every inner child has a larger number than its parent
+    // A group cut off at a frontier: references numbered owner.size() + j stand for the root (wide node 0)
+    // of the j-th of the n_pending groups that follow this one.
+    size_t n_pending = 0;
 };
 
 // Which inner nodes stay (become wide nodes) and which dissolve into their parent's slots,
@@ -175,13 +178,19 @@ void plan_collapse(const BVHNodeInfo *nodes, const int32_t *roots, size_t n_root
     }
 }
 
+void wide_group_heights(WideGroup &g, uint32_t inner_kind, bool quantised, const uint8_t *pending_height);
+
 template <class IsLeaf, class LeafRef>
 void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *roots, size_t n_roots, IsLeaf is_leaf,
                       LeafRef leaf_ref, bool leaf_box_of_parent, uint32_t inner_kind, bool quantised,
-                      std::vector<uint32_t> &wide_of, CollapsePlan &plan, WideGroup &g) {
+                      std::vector<uint32_t> &wide_of, CollapsePlan &plan, WideGroup &g, size_t frontier = 0,
+                      std::vector<int32_t> *pending = nullptr) {
+    // frontier > 0: wide nodes are made breadth first, and only until that many wait to be made; those are
+    // handed back in `pending` (their subtrees become groups of their own, built side by side) instead.
     const uint32_t stride = quantised ? 1u : 2u;  // slots per wide node
     plan_collapse(nodes, roots, n_roots, n_nodes, is_leaf, plan);
     std::vector<int32_t> work;
+    size_t head = 0;  // breadth first: work[head ...] is the queue
     auto wide_index = [&](int32_t node) {  // number of the node's wide node within the group (created on first use)
         if(wide_of[node] == REF_NONE) {
             wide_of[node] = (uint32_t)g.owner.size();
@@ -193,9 +202,14 @@ void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *r
     };
     for(size_t r = 0; r < n_roots; r++)
         if(roots[r] >= 0 && (size_t)roots[r] < n_nodes && !is_leaf(roots[r])) wide_index(roots[r]);
-    while(!work.empty()) {
-        const int32_t n = work.back();
-        work.pop_back();
+    while(frontier ? head < work.size() && work.size() - head < frontier : !work.empty()) {
+        int32_t n;
+        if(frontier) {
+            n = work[head++];
+        } else {
+            n = work.back();
+            work.pop_back();
+        }
         struct Item { int32_t node, parent; bool pair; } items[4];  // pair: `node` is an inner node, its two leaves share the slot
         int cnt = 0;
         auto bottom = [&](int32_t c) { return plan.pairs && !is_leaf(c) && is_leaf(nodes[c].lsIndex) && is_leaf(nodes[c].rsIndex); };
@@ -268,8 +282,28 @@ void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *r
             }
         }
     }
-    // heights, children before parents: in creation order a child comes after its parent unless
-    // subtrees are shared; then order by the reference index (a child's is larger than its parent's)
+    if(frontier) {
+        // what still waits was numbered last, in queue order: take those numbers back
+        const size_t n_wait = work.size() - head, n_top = g.owner.size() - n_wait;
+        for(size_t j = 0; j < n_wait; j++) {
+            const int32_t node = work[head + j];
+            if(wide_of[node] != n_top + j) abort();  // (numbering is by creation, creation is by queue order)
+            wide_of[node] = REF_NONE;
+            pending->push_back(node);
+        }
+        g.owner.resize(n_top);
+        g.recs.resize(n_top * stride);
+        g.n_pending = n_wait;
+        return;  // heights: once the groups below are known
+    }
+    wide_group_heights(g, inner_kind, quantised, nullptr);
+}
+
+// Heights of a group's wide subtrees, children before parents: in creation order a child comes after
+// its parent unless subtrees are shared; then order by the reference index (a child's is larger than
+// its parent's).  pending_height[j]: height of the j-th group cut off below this one.
+void wide_group_heights(WideGroup &g, uint32_t inner_kind, bool quantised, const uint8_t *pending_height) {
+    const uint32_t stride = quantised ? 1u : 2u;
     const size_t n_wide = g.owner.size();
     g.height.assign(n_wide, 1);
     std::vector<uint32_t> order;
@@ -283,7 +317,10 @@ void build_wide_group(const BVHNodeInfo *nodes, size_t n_nodes, const int32_t *r
         const uint32_t *c = wide_refs(&g.recs[k * stride], quantised);
         int h = 1;
         for(int i = 0; i < 4; i++)
-            if(c[i] != REF_NONE && (c[i] >> 30) == inner_kind) h = std::max<int>(h, 1 + g.height[c[i] & REF_INDEX_MASK]);
+            if(c[i] != REF_NONE && (c[i] >> 30) == inner_kind) {
+                const size_t ck = c[i] & REF_INDEX_MASK;
+                h = std::max<int>(h, 1 + (ck < n_wide ? g.height[ck] : pending_height[ck - n_wide]));
+            }
         g.height[k] = (uint8_t)std::min(h, 255);
     }
 }
@@ -327,14 +364,74 @@ uint32_t build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::v
     plan.pairs = pairs;
     plan.cost.resize(3 * n_nodes);
     plan.dec.assign(n_nodes, 0);
-    std::vector<WideGroup> groups(disjoint ? roots.size() : 1);
-    if(disjoint)
-        parallel_items(roots.size(), layout_threads(), [&](size_t r) {
-            build_wide_group(nodes, n_nodes, &roots[r], 1, is_leaf, leaf_ref, leaf_box_of_parent, inner_kind, quantised, wide_of, plan, groups[r]);
+    // Trees that share nothing are built side by side.  A tree of BIG_TREE nodes or more is cut as well: its top
+    // is made breadth first until FRONTIER wide nodes wait, and the subtrees under those become groups of their own
+    // (the cost plan, bottom-up, is first made for the subtrees under a frontier of the binary tree in the same way).
+    // Where the cuts fall depends on the trees alone, not on the number of threads: the layout is the same on any machine.
+    constexpr size_t BIG_TREE = (size_t)1 << 17, FRONTIER = 256;
+    std::vector<WideGroup> groups(1);
+    if(disjoint) {
+        const unsigned threads = layout_threads();
+        std::vector<uint8_t> big(roots.size(), 0);
+        if(n_nodes >= BIG_TREE) {
+            std::vector<uint32_t> size(n_nodes, 1);  // (children come after their parents)
+            for(size_t i = n_nodes; i-- > 0;)
+                if(!is_leaf((int32_t)i)) size[i] = 1 + size[nodes[i].lsIndex] + size[nodes[i].rsIndex];
+            std::vector<int32_t> plan_roots;
+            for(size_t r = 0; r < roots.size(); r++) {
+                if(size[roots[r]] < BIG_TREE) continue;
+                big[r] = 1;
+                // the FRONTIER largest subtrees found by always opening the largest
+                std::vector<int32_t> open{roots[r]};
+                auto smaller = [&](int32_t a, int32_t b) { return size[a] != size[b] ? size[a] < size[b] : a > b; };
+                while(open.size() < FRONTIER && size[open.front()] > 64) {
+                    std::pop_heap(open.begin(), open.end(), smaller);
+                    const int32_t n = open.back();
+                    open.pop_back();
+                    for(int32_t c : {nodes[n].lsIndex, nodes[n].rsIndex}) {
+                        open.push_back(c);
+                        std::push_heap(open.begin(), open.end(), smaller);
+                    }
+                }
+                plan_roots.insert(plan_roots.end(), open.begin(), open.end());
+            }
+            parallel_items(plan_roots.size(), threads, [&](size_t i) { plan_collapse(nodes, &plan_roots[i], 1, n_nodes, is_leaf, plan); });
+        }
+        // tops (whole trees where small), then what was cut off below them
+        std::vector<WideGroup> tops(roots.size());
+        std::vector<std::vector<int32_t>> pending(roots.size());
+        parallel_items(roots.size(), threads, [&](size_t r) {
+            build_wide_group(nodes, n_nodes, &roots[r], 1, is_leaf, leaf_ref, leaf_box_of_parent, inner_kind, quantised, wide_of, plan, tops[r],
+                             big[r] ? FRONTIER : 0, &pending[r]);
         });
-    else
+        std::vector<size_t> top_at(roots.size());
+        std::vector<int32_t> sub_root;
+        std::vector<size_t> sub_at;
+        size_t n_groups = 0;
+        for(size_t r = 0; r < roots.size(); r++) {
+            top_at[r] = n_groups++;
+            for(int32_t node : pending[r]) {
+                sub_root.push_back(node);
+                sub_at.push_back(n_groups++);
+            }
+        }
+        groups.resize(n_groups);
+        for(size_t r = 0; r < roots.size(); r++) groups[top_at[r]] = std::move(tops[r]);
+        parallel_items(sub_root.size(), threads, [&](size_t i) {
+            build_wide_group(nodes, n_nodes, &sub_root[i], 1, is_leaf, leaf_ref, leaf_box_of_parent, inner_kind, quantised, wide_of, plan,
+                             groups[sub_at[i]]);
+        });
+        for(size_t r = 0; r < roots.size(); r++) {
+            if(!big[r]) continue;
+            WideGroup &g = groups[top_at[r]];
+            std::vector<uint8_t> below(g.n_pending);
+            for(size_t j = 0; j < g.n_pending; j++) below[j] = groups[top_at[r] + 1 + j].height[0];
+            wide_group_heights(g, inner_kind, quantised, below.data());
+        }
+    } else {
         build_wide_group(nodes, n_nodes, roots.data(), roots.size(), is_leaf, leaf_ref, leaf_box_of_parent, inner_kind, quantised,
                          wide_of, plan, groups[0]);
+    }
     // merge: group g's wide node k becomes slot slot_base + stride * (first[g] + k)
     std::vector<size_t> first(groups.size() + 1, 0);
     for(size_t g = 0; g < groups.size(); g++) first[g + 1] = first[g] + groups[g].owner.size();
@@ -345,10 +442,15 @@ uint32_t build_wide_nodes(const BVHNodeInfo *nodes, size_t n_nodes, const std::v
     parallel_items(groups.size(), layout_threads(), [&](size_t gi) {
         WideGroup &g = groups[gi];
         const uint32_t base = slot_base + stride * (uint32_t)first[gi];
-        for(size_t k = 0; k < g.owner.size(); k++) {
+        const size_t n_own = g.owner.size();
+        for(size_t k = 0; k < n_own; k++) {
             uint32_t *c = wide_refs(&g.recs[k * stride], quantised);
             for(int i = 0; i < 4; i++)
-                if(c[i] != REF_NONE && (c[i] >> 30) == inner_kind) c[i] = make_ref(inner_kind, base + stride * (c[i] & REF_INDEX_MASK));
+                if(c[i] != REF_NONE && (c[i] >> 30) == inner_kind) {
+                    const size_t ck = c[i] & REF_INDEX_MASK;
+                    // (a number past the group's own nodes: the root of one of the groups cut off below it)
+                    c[i] = make_ref(inner_kind, ck < n_own ? base + stride * (uint32_t)ck : slot_base + stride * (uint32_t)first[gi + 1 + (ck - n_own)]);
+                }
             wide_of[g.owner[k]] = base + stride * (uint32_t)k;
             wide_height[first[gi] + k] = g.height[k];
         }

@@ -1,7 +1,9 @@
 #include "bvh_builder.h"
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <queue>
+#include <thread>
 #include <utility>
 
 namespace rta {
@@ -18,10 +20,55 @@ struct Builder {
     const Box *boxes;
     std::vector<int> order;        // primitive ids, in the order the reference's vector holds them
     std::vector<KeyIdx> sorted[3]; // per-axis scratch, sized n once
-    std::vector<float> suf_surface;
+    std::vector<float> suf_surface[3];  // per axis, so that the three sweeps of a large node can run side by side
     SahTree *tree;
+    // Threads beyond the calling one that the build may still start.  Two kinds of work are handed
+    // out, both leaving the result untouched: the three axis sweeps of a large node (each sweep keeps
+    // its own best split; they are then compared in axis order with the reference's strict `<`), and
+    // the two subtrees of a node (disjoint index ranges, and node numbers that do not depend on who
+    // builds what: a subtree over n primitives has 2n - 1 nodes, numbered in preorder from its root).
+    std::atomic<int> spare_threads{0};
+    static constexpr int PARALLEL_SWEEP_MIN = 1 << 17, PARALLEL_SUBTREE_MIN = 1 << 14;
 
-    // Builds the subtree over order[lo, hi) and returns its node index.
+    bool take_threads(int k) {
+        int have = spare_threads.load(std::memory_order_relaxed);
+        while(have >= k)
+            if(spare_threads.compare_exchange_weak(have, have - k, std::memory_order_relaxed)) return true;
+        return false;
+    }
+    void give_threads(int k) { spare_threads.fetch_add(k, std::memory_order_relaxed); }
+
+    // One axis of the sweep over order[lo, lo + n): sorts by box centre and returns the cheapest
+    // split of this axis that beats `limit` (cost, index), or (limit, -1).
+    std::pair<float, int> sweep_axis(int d, int lo, int n, float limit) {
+        KeyIdx *s = sorted[d].data() + lo;
+        for(int i = 0; i < n; i++) {
+            const Box &b = boxes[order[lo + i]];
+            s[i].key = (b.mi[d] + b.mx[d]) * 0.5f;
+            s[i].idx = order[lo + i];
+        }
+        std::sort(s, s + n, [](const KeyIdx &a, const KeyIdx &b) { return a.key < b.key; });
+        float *suf = suf_surface[d].data() + lo;
+        Box acc;
+        for(int i = n - 1; i >= 0; i--) {
+            acc.combine(boxes[s[i].idx]);
+            suf[i] = acc.surface();
+        }
+        float best = limit;
+        int best_i = -1;
+        Box pre;
+        for(int i = 0; i < n - 1; i++) {
+            pre.combine(boxes[s[i].idx]);
+            float c = pre.surface() * (float)(i + 1) + suf[i + 1] * (float)(n - i - 1);
+            if(c < best) {
+                best = c;
+                best_i = i;
+            }
+        }
+        return {best, best_i};
+    }
+
+    // Builds the subtree over order[lo, hi) into nodes[me ...] (preorder) and returns me.
     //
     // Tie order matters: std::sort is not stable, so the permutation it produces for
     // equal keys depends on the input order and on the comparator's answers only.
@@ -29,11 +76,9 @@ struct Builder {
     // `centre[d] < centre[d]`; sorting (key, id) pairs that start in the same order
     // with the same predicate walks libstdc++'s introsort through the same steps and
     // ends in the same permutation, at 8 bytes per element instead of 40.
-    int build(int lo, int hi) {
+    int build(int lo, int hi, int me) {
         int n = hi - lo;
         assert(n > 0);
-        int me = (int)tree->nodes.size();
-        tree->nodes.emplace_back();
         if(n == 1) {
             SahNode &leaf = tree->nodes[me];
             leaf.box = boxes[order[lo]];
@@ -45,34 +90,31 @@ struct Builder {
         Box all;
         for(int i = lo; i < hi; i++) all.combine(boxes[order[i]]);
 
-        int bs_d = 0, bs_i = 0;
-        float bs_cost = (float)n * all.surface();
-        for(int d = 0; d < 3; d++) {
-            KeyIdx *s = sorted[d].data() + lo;
-            for(int i = 0; i < n; i++) {
-                const Box &b = boxes[order[lo + i]];
-                s[i].key = (b.mi[d] + b.mx[d]) * 0.5f;
-                s[i].idx = order[lo + i];
-            }
-            std::sort(s, s + n, [](const KeyIdx &a, const KeyIdx &b) { return a.key < b.key; });
-
-            float *suf = suf_surface.data() + lo;
-            Box acc;
-            for(int i = n - 1; i >= 0; i--) {
-                acc.combine(boxes[s[i].idx]);
-                suf[i] = acc.surface();
-            }
-            Box pre;
-            for(int i = 0; i < n - 1; i++) {
-                pre.combine(boxes[s[i].idx]);
-                float c = pre.surface() * (float)(i + 1) + suf[i + 1] * (float)(n - i - 1);
-                if(c < bs_cost) {
-                    bs_cost = c;
-                    bs_d = d;
-                    bs_i = i;
-                }
-            }
+        // The reference runs the axes one after the other against ONE running best with a strict `<`
+        // (BVH.cpp:42-67).  Sweeping each axis against the initial cost and then taking, in axis order,
+        // the first that is strictly cheaper gives the same (axis, index): within an axis the first
+        // index of the axis' minimum wins either way, and an axis that does not beat its predecessors'
+        // best changes nothing either way.
+        const float initial = (float)n * all.surface();
+        std::pair<float, int> ax[3];
+        if(n >= PARALLEL_SWEEP_MIN && take_threads(2)) {
+            std::thread t1([&] { ax[1] = sweep_axis(1, lo, n, initial); });
+            std::thread t2([&] { ax[2] = sweep_axis(2, lo, n, initial); });
+            ax[0] = sweep_axis(0, lo, n, initial);
+            t1.join();
+            t2.join();
+            give_threads(2);
+        } else {
+            for(int d = 0; d < 3; d++) ax[d] = sweep_axis(d, lo, n, initial);
         }
+        int bs_d = 0, bs_i = 0;
+        float bs_cost = initial;
+        for(int d = 0; d < 3; d++)
+            if(ax[d].second >= 0 && ax[d].first < bs_cost) {
+                bs_cost = ax[d].first;
+                bs_d = d;
+                bs_i = ax[d].second;
+            }
         // left keeps the first bs_i+1 of the winning order; right receives the rest
         // back to front (the reference moves them with pop_back/push_back, BVH.cpp:71-75)
         const KeyIdx *w = sorted[bs_d].data() + lo;
@@ -80,8 +122,16 @@ struct Builder {
         for(int i = 0; i < nl; i++) order[lo + i] = w[i].idx;
         for(int i = nl; i < n; i++) order[lo + i] = w[n - 1 - (i - nl)].idx;
 
-        int l = build(lo, lo + nl);
-        int r = build(lo + nl, hi);
+        const int l = me + 1, r = me + 2 * nl;  // preorder: the left subtree's 2 nl - 1 nodes sit between
+        if(n >= PARALLEL_SUBTREE_MIN && nl >= PARALLEL_SUBTREE_MIN / 8 && n - nl >= PARALLEL_SUBTREE_MIN / 8 && take_threads(1)) {
+            std::thread tl([&] { build(lo, lo + nl, l); });
+            build(lo + nl, hi, r);
+            tl.join();
+            give_threads(1);
+        } else {
+            build(lo, lo + nl, l);
+            build(lo + nl, hi, r);
+        }
         SahNode &node = tree->nodes[me];
         node.box = all;
         node.left = l;
@@ -102,18 +152,21 @@ BVHNodeInfo make_node(const Box &b) {
 
 }  // namespace
 
-void build_sah_tree(const Box *boxes, int n, SahTree &out) {
+void build_sah_tree(const Box *boxes, int n, SahTree &out, int n_threads) {
     assert(n > 0);
     Builder b;
     b.boxes = boxes;
     b.order.resize(n);
     for(int i = 0; i < n; i++) b.order[i] = i;
-    for(int d = 0; d < 3; d++) b.sorted[d].resize(n);
-    b.suf_surface.resize(n);
+    for(int d = 0; d < 3; d++) {
+        b.sorted[d].resize(n);
+        b.suf_surface[d].resize(n);
+    }
     out.nodes.clear();
-    out.nodes.reserve(2 * (size_t)n - 1);
+    out.nodes.resize(2 * (size_t)n - 1);
     b.tree = &out;
-    out.root = b.build(0, n);
+    b.spare_threads = n_threads > 1 ? n_threads - 1 : 0;
+    out.root = b.build(0, n, 0);
 }
 
 void flatten_mesh_trees(const std::vector<SahTree> &trees, const std::vector<int> &tri_base,

@@ -45,8 +45,10 @@ struct SahTree {
     int root = -1;
 };
 
-// Builds the tree over n primitive boxes (n >= 1).  One primitive per leaf.
-void build_sah_tree(const Box *boxes, int n, SahTree &out);
+// Builds the tree over n primitive boxes (n >= 1).  One primitive per leaf.  n_threads > 1 lets
+// a large tree use that many threads (axis sweeps of big nodes and sibling subtrees side by side);
+// the tree is the same whatever the number.
+void build_sah_tree(const Box *boxes, int n, SahTree &out, int n_threads = 1);
 
 // Mesh level.  trees[m] was built over the boxes of mesh m's triangles in array
 // order; tri_base[m] is the index of its first triangle in the concatenated

@@ -53,16 +53,19 @@ void build_mesh_set(const TriangleRec *tris, const int *tri_count, int n_mesh, i
         base += tri_count[m];
     }
     std::vector<SahTree> trees(n_mesh);
+    // Meshes are built side by side; when there are fewer meshes than threads, each tree also gets a share
+    // of the threads for itself (a single huge mesh gets all of them).
+    const int per_tree = n_threads > n_mesh ? (n_threads + n_mesh - 1) / n_mesh : 1;
     auto work = [&](int m) {
         int n = tri_count[m];
         std::vector<Box> boxes(n);
         const TriangleRec *t = tris + out.tri_base[m];
         for(int i = 0; i < n; i++)
             for(int v = 0; v < 3; v++) boxes[i].add_point(&t[i].ver[v * 3]);
-        build_sah_tree(boxes.data(), n, trees[m]);
+        build_sah_tree(boxes.data(), n, trees[m], per_tree);
     };
     if(n_threads <= 1 || n_mesh == 1) {
-        for(int m = 0; m < n_mesh; m++) work(m);
+        for(int m = 0; m < n_mesh; m++) work(m);  // (one mesh: its tree uses the threads inside)
     } else {
         std::atomic<int> next(0);
         std::vector<std::thread> pool;

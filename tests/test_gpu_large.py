@@ -81,3 +81,38 @@ def test_10m_triangles_4k_depth8_ordered_equals_reference_order(gpu_ctx, small_s
         assert _bit_equal(got[k], ref[k]), k
     p.destroy()
     sb.release()
+
+
+def test_one_mesh_of_a_million_triangles_vs_oracle(gpu_ctx, small_sky, oracle_mod):
+    """ONE mesh large enough for the host builder and the re-layout to split its tree over threads
+    (reference build: src/BVH.cpp:40-82; the layout cuts trees of 2^17 nodes and more): the frame
+    must still equal the oracle's, and the ordered traversal the reference-order one."""
+    from raytracing_amd import device, scene
+    k = 708
+    u = np.linspace(0.0, 80.0, k + 1)
+    x, z = np.meshgrid(u, u, indexing="ij")
+    y = 1.5 * np.sin(0.21 * x) * np.cos(0.17 * z) + 0.6 * np.sin(0.53 * x + 1.3) * np.sin(0.47 * z + 0.4) + 0.15 * np.sin(2.1 * x) * np.cos(1.9 * z)
+    b = scene.SceneBuilder()
+    m = b.add_mesh(scene._grid_mesh(np.stack([x, y, z], -1), k, k, 4.0))
+    b.add_instance(m, scene.transform_matrix((-40.0, 0.0, -40.0)),
+                   dict(type=1, albedo=(0.8, 0.7, 0.6), roughness=np.float32(0.3), metallic=np.float32(1.0), tex=-1, ior=np.float32(1.5)))
+    sd = b.finish(0)
+    assert len(sd.tri_count) == 1 and len(sd.triangles) > 1_000_000
+    w, h, depth = 384, 216, 4
+    sb = device.SceneBuffers(gpu_ctx, sd, small_sky)
+    prm = scene.make_params(w, h, scene.synthetic_camera(), small_sky, spp=1, max_depth=depth)
+    images = []
+    for mode in (0, 1):
+        p = device.PathTracingPass(gpu_ctx, w, h)
+        p.bind_scene(sb)
+        p.set_traversal(mode)
+        p.set_params(prm)
+        p.draw()
+        images.append(p.download())
+        p.destroy()
+    ref, _ = oracle_mod.OracleScene(sd, small_sky).render(prm)
+    for key in ref:
+        assert _bit_equal(images[0][key], ref[key]), key
+        assert _bit_equal(images[1][key], ref[key]), key
+    assert (images[0]["instanceIndex"] >= 0).mean() > 0.3
+    sb.release()

@@ -81,6 +81,31 @@ def test_live_against_compiled_reference(casa, oracle_mod):
     assert np.array_equal(siz, sd.mesh_siz) and np.array_equal(depth, sd.mesh_depth)
 
 
+def _tie_heavy_triangles(n, seed):
+    rng = np.random.default_rng(seed)
+    tris = np.zeros((n, 24), np.float32)
+    # coordinates on a coarse half-unit grid: many equal box centres on every axis, so that the sort's tie order matters
+    tris[:, :9] = (rng.integers(0, 40, (n, 1, 3)) + rng.integers(0, 3, (n, 3, 3)) * 0.5).reshape(n, 9)
+    return tris
+
+
+def test_one_large_mesh_builds_the_same_tree_on_any_number_of_threads(oracle_mod):
+    """A single mesh big enough for the builder to split its own work: the axis sweeps of nodes of
+    2^17 primitives and more run side by side, and so do sibling subtrees (reference algorithm:
+    src/BVH.cpp:40-82, whose output the tree must equal byte for byte)."""
+    n = 300_000
+    tris = _tie_heavy_triangles(n, 11)
+    one = _build(np.array([n], np.int32), tris, threads=1)
+    for threads in (2, 3, 8):
+        many = _build(np.array([n], np.int32), tris, threads=threads)
+        assert many.mesh_nodes.tobytes() == one.mesh_nodes.tobytes(), threads
+        assert np.array_equal(many.mesh_siz, one.mesh_siz) and np.array_equal(many.mesh_depth, one.mesh_depth)
+    if oracle_mod.have_ref():
+        nodes, siz, depth = oracle_mod.ref_mesh_bvh(one)
+        assert np.array_equal(np.frombuffer(one.mesh_nodes.tobytes(), np.uint8), nodes)
+        assert np.array_equal(siz, one.mesh_siz) and np.array_equal(depth, one.mesh_depth)
+
+
 def test_glm_inverse_and_product_bit_exact():
     from raytracing_amd import scene
     g = np.load(os.path.join(GOLDEN, "glm_mat.npz"))

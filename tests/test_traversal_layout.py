@@ -136,3 +136,21 @@ def test_random_scenes_keep_every_reference_leaf_reachable():
             assert counts[2] >= len(sd.triangles)
 
     prop()
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_a_tree_large_enough_to_be_cut_into_groups(fmt):
+    """One mesh of 2^17 reference nodes or more: its four-wide tree is built as a top part plus the
+    subtrees under a frontier, side by side, and stitched; a second, small mesh rides along so that
+    both kinds of group sit in one buffer.  The independent verifier must still find every triangle
+    reachable, every box contained and the height bound sufficient."""
+    rng = np.random.default_rng(17)
+    sb = scene.SceneBuilder()
+    sb.add_instance(sb.add_mesh(_random_mesh(rng, 90_000, 10.0)))
+    sb.add_instance(sb.add_mesh(_random_mesh(rng, 700, 1.0, (30, 0, 0))))
+    sb.add_instance(0, scene.transform_matrix(position=(0, 25, 0)))
+    sd = sb.finish()
+    assert 2 * 90_000 - 1 >= 1 << 17
+    rc, counts, err = check_layout(sd, fmt)
+    assert rc == 0, err
+    assert counts[2] > len(sd.triangles)
