@@ -263,11 +263,14 @@ def main():
             for s in list(my_samples)[:2]:
                 draw(s, accum_mode)
             ctx.synchronize()
-            t1 = time.perf_counter()
+            each = []
             for s in list(my_samples)[:n_prof]:
+                t1 = time.perf_counter()
                 draw(s, accum_mode)
                 ctx.synchronize()
-            serial_ms = (time.perf_counter() - t1) / n_prof * 1e3
+                each.append((time.perf_counter() - t1) * 1e3)
+            # (the median: one draw that meets a busy host thread or a clock ramp does not move it; the mean rides along)
+            serial_ms, serial_mean_ms = float(np.median(each)), float(np.mean(each))
             # (b) per-kernel times of the vertex-by-vertex chain (tail launch off, so that every ray of the
             #     draws is traced by the kernels that are timed)
             p.set_tail_threshold(0)
@@ -285,6 +288,7 @@ def main():
             note("per-kernel profiling pass done")
             prof["draws"] = n_prof
             prof["serial_ms_per_step"] = serial_ms
+            prof["serial_mean_ms_per_step"] = serial_mean_ms
             # every BVH traversal launch of the draws: extend at vertex 0, then per vertex one launch
             # tracing shadow(d) + extend(d+1) rays, each followed by the small reference-order re-trace
             dominant = ("path_trace_fast_kernel + extend_fast_kernel + extend_kernel",
@@ -466,6 +470,7 @@ def main():
                 if "draws" in prof:
                     out["kernel_ms"]["over_draws"] = prof["draws"]
                     out["kernel_ms"]["one_draw_in_flight_ms_per_step"] = prof["serial_ms_per_step"]
+                    out["kernel_ms"]["one_draw_in_flight_mean_ms_per_step"] = prof["serial_mean_ms_per_step"]
                     if b_ray is not None:
                         # what the whole pipelined frame sustains, extend rays only
                         out["roofline"]["measured_on"] = "%d draws issued one at a time after the timed region" % prof["draws"]
