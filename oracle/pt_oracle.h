@@ -6,13 +6,19 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may.
  *
  * Pinning: the reference has no tests or golden vectors for this path and its GLSL cannot
- * be executed in the build container (no GL context).  What IS pinned by running the
- * reference's own compiled C++ (oracle/_ref/ref_harness): the BVH arrays this oracle
- * traverses, the slab / Moller-Trumbore arithmetic (against the CPU picking path
- * BVH.cpp:89-114, which differs from the shader only in strict-vs-inclusive comparisons
- * and visiting order), glm::inverse, RGBE and JPEG decode.  Everything above the
- * intersection routine (BSDFs, sky sampling, accumulation) is "parity unpinned": it
- * follows the GLSL text line by line but was never compared with GLSL output.
+ * be executed as GLSL in the build container (no GL context).  It is pinned by running the
+ * reference's own source text, compiled here:
+ *   - its C++ (oracle/_ref/ref_harness): the BVH arrays this oracle traverses, the slab /
+ *     Moller-Trumbore arithmetic (against the CPU picking path BVH.cpp:89-114, which differs
+ *     from the shader only in strict-vs-inclusive comparisons and visiting order),
+ *     glm::inverse, RGBE and JPEG decode;
+ *   - its GLSL compiled as C++ against the glm headers it vendors (oracle/glsl_kat.py,
+ *     oracle/glsl_frame.py; fixtures tests/golden/glsl_bsdf_kat.npz, glsl_frame_casa.npz):
+ *     both BSDFs and the Sobol sampler query by query, and the whole fragment shader one
+ *     main() per pixel on six configurations.  With the shader's sin / cos / atan / asin / pow
+ *     resolved to the recipe below, every output word of those frames equals this oracle's.
+ * Still unpinned: what GLSL itself leaves open (a driver's transcendentals and texture
+ * filtering), and the inputs of the raster pass.
  *
  * Conventions chosen where GLSL leaves behaviour open (the HIP path makes the same ones):
  *   - no fused multiply-add anywhere (build with -ffp-contract=off);
