@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
 #include <random>
 #include <vector>
 #include "raytracing_amd.h"
@@ -18,7 +20,7 @@ static int fails = 0;
         }                                                                   \
     } while(0)
 
-int main() {
+int main(int argc, char **argv) {
     std::mt19937 rng(3);
     std::uniform_real_distribution<float> u(-1.0f, 1.0f);
     const int tri_counts[] = {1, 2, 3, 257, 5000, 64};
@@ -150,6 +152,92 @@ int main() {
         (void)pt_host_mat4_inverse(m, inv);
         EXPECT(pt_host_mat4_mul(m, inv, prod) == PT_OK);
         EXPECT(pt_host_camera_projection(1.0f, 1000.0f, 640, 480, proj) == PT_OK);
+    }
+    // ONE mesh large enough for the builder and the re-layout to split its tree over threads
+    // (axis sweeps of nodes of 2^17 primitives side by side, sibling subtrees in parallel, the
+    // wide-node layout cut at a frontier): the threaded parts under ThreadSanitizer
+    {
+        const int n = 140000;
+        std::vector<float> big((size_t)n * 24, 0.0f);
+        for(int t = 0; t < n; t++) {
+            // coordinates on a coarse grid: many equal box centres
+            const float cx = (float)(rng() % 60), cy = (float)(rng() % 60), cz = (float)(rng() % 60);
+            for(int k = 0; k < 9; k++) big[(size_t)t * 24 + k] = (k % 3 == 0 ? cx : k % 3 == 1 ? cy : cz) + 0.5f * (float)(rng() % 3);
+        }
+        int32_t count = n, s1 = 0, d1 = 0;
+        float box[6];
+        std::vector<uint8_t> nodes1((size_t)(2 * n - 1) * 48), nodes8(nodes1.size());
+        EXPECT(pt_host_build_mesh_bvh(big.data(), &count, 1, 1, nodes1.data(), box, &s1, &d1) == PT_OK);
+        EXPECT(pt_host_build_mesh_bvh(big.data(), &count, 1, 8, nodes8.data(), box, &s1, &d1) == PT_OK);
+        EXPECT(nodes1 == nodes8);
+        float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        int32_t mi = 0, mp = 0, st[2];
+        std::vector<uint8_t> inst1(112), scene1(48);
+        EXPECT(pt_host_build_scene(box, &s1, &d1, 1, ident, &mi, &mp, 1, inst1.data(), scene1.data(), st) == PT_OK);
+        EXPECT(pt_host_check_traversal_layout(nodes8.data(), (size_t)(2 * n - 1), big.data(), (size_t)n, scene1.data(), 1, inst1.data(), 1, 1,
+                                              counts) == PT_OK);
+    }
+    // glTF binary reader: the demo model, every truncation class, and random damage to header,
+    // JSON and buffer bytes; a damaged file is refused or read, never over-read
+    if(argc > 1) {
+        FILE *f = fopen(argv[1], "rb");
+        EXPECT(f != nullptr);
+        if(f) {
+            fseek(f, 0, SEEK_END);
+            std::vector<uint8_t> file((size_t)ftell(f));
+            fseek(f, 0, SEEK_SET);
+            EXPECT(fread(file.data(), 1, file.size(), f) == file.size());
+            fclose(f);
+            auto read_all = [&](const std::vector<uint8_t> &bytes, bool must_work) {
+                pt_glb *g = nullptr;
+                const int rc = pt_host_glb_open_memory(bytes.data(), bytes.size(), &g);
+                if(must_work) EXPECT(rc == PT_OK);
+                if(rc != PT_OK) return;
+                pt_glb_info gi;
+                EXPECT(pt_host_glb_info(g, &gi) == PT_OK);
+                std::vector<int32_t> tc(gi.n_meshes), mesh_index(gi.n_instances), mat_index(gi.n_instances), mptr(gi.n_instances);
+                std::vector<float> tri((size_t)gi.n_triangles * 24), l2w((size_t)gi.n_instances * 16);
+                std::vector<pt_glb_material> mats(gi.n_materials);
+                EXPECT(pt_host_glb_meshes(g, tc.data(), tri.data()) == PT_OK);
+                EXPECT(pt_host_glb_materials(g, mats.data()) == PT_OK);
+                EXPECT(pt_host_glb_instances(g, nullptr, mesh_index.data(), mat_index.data(), l2w.data()) == PT_OK);
+                for(int k = 0; k < gi.n_textures; k++) {
+                    const void *b = nullptr;
+                    size_t nb = 0;
+                    int32_t img = 0;
+                    if(pt_host_glb_texture(g, k, &b, &nb, &img) == PT_OK && nb > 0) {
+                        volatile uint8_t first = static_cast<const uint8_t *>(b)[0], last = static_cast<const uint8_t *>(b)[nb - 1];
+                        (void)first;
+                        (void)last;
+                    }
+                }
+                const int64_t need = pt_host_glb_material_stream(g, nullptr, 0, nullptr);
+                if(need > 0) {
+                    std::vector<float> stream((size_t)need);
+                    EXPECT(pt_host_glb_material_stream(g, stream.data(), stream.size(), mptr.data()) == need);
+                }
+                EXPECT(pt_host_glb_close(g) == PT_OK);
+            };
+            read_all(file, true);
+            uint32_t json_len = 0;
+            memcpy(&json_len, &file[12], 4);
+            for(size_t cut : {(size_t)0, (size_t)11, (size_t)12, (size_t)19, (size_t)20, (size_t)20 + json_len / 2, (size_t)20 + json_len,
+                              (size_t)24 + json_len, file.size() / 2, file.size() - 1}) {
+                std::vector<uint8_t> part(file.begin(), file.begin() + std::min(cut, file.size()));  // exact-size buffer: over-reads are seen
+                read_all(part, false);
+            }
+            for(int rep = 0; rep < 300; rep++) {
+                std::vector<uint8_t> junk = file;
+                const size_t span = rep % 3 == 0 ? 28 : (rep % 3 == 1 ? 20 + json_len : junk.size());
+                const int hits = 1 + (int)(rng() % 4);
+                for(int k = 0; k < hits; k++) {
+                    const size_t at = rng() % span;
+                    // digits become other digits now and then (indices, counts, offsets stay parseable but wrong)
+                    junk[at] = (junk[at] >= '0' && junk[at] <= '9' && rng() % 2) ? (uint8_t)('0' + rng() % 10) : (uint8_t)rng();
+                }
+                read_all(junk, false);
+            }
+        }
     }
     printf(fails ? "FAILED %d\n" : "host sanitize run ok\n", fails);
     return fails ? 1 : 0;
