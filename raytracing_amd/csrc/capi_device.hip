@@ -192,6 +192,19 @@ int host_view(pt_buf *b, std::vector<uint8_t> &tmp, const uint8_t **out) {
     return PT_OK;
 }
 
+// The upload shadow of the triangle buffer is read by the mesh-level re-layout only: once that is
+// done a large one is given back (0.96 GB for 10 M triangles); a later mesh-level re-layout of the
+// same buffer (other node format, instances rooted inside a tree) reads the device copy instead.
+// The BVH and instance buffers keep theirs: moving instances re-lays out the scene level every frame.
+void release_large_shadow(pt_buf *b) {
+    size_t least = (size_t)64 << 20;
+    if(const char *e = getenv("RTA_SHADOW_RELEASE_MIN")) least = (size_t)strtoull(e, nullptr, 10);  // (test aid)
+    if(b->shadow_valid && b->shadow.size() >= least) {
+        b->shadow_valid = false;
+        std::vector<uint8_t>().swap(b->shadow);
+    }
+}
+
 int upload_array(pt_ctx *ctx, DeviceArray &d, const void *src, size_t bytes) {
     // the array may still be read by draws in flight
     JOIN_TRY(ctx);
@@ -267,6 +280,9 @@ int prepare_scene(pt_pass *p) {
                 p->mesh_level_builds++;
                 slot_mark(p, PT_SLOT_TRIANGLE);
                 slot_mark(p, PT_SLOT_MESH_BVH);
+                tris = nullptr;
+                std::vector<uint8_t>().swap(t_tris);
+                release_large_shadow(b_tris);
             }
             AccelSceneLevel sl;
             bool missing_root = false;
@@ -285,6 +301,7 @@ int prepare_scene(pt_pass *p) {
                 std::vector<TNode>().swap(ml.slots);
                 p->mesh_level_valid = true;
                 p->mesh_level_builds++;
+                release_large_shadow(b_tris);
                 ok = build_accel_scene_level(mesh_n, n_mesh_nodes, p->mesh_level, reinterpret_cast<const BVHNodeInfo *>(scene),
                                              b_scene->bytes / sizeof(BVHNodeInfo), ii, n_inst, sl, err);
             }
