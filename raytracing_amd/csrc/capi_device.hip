@@ -192,14 +192,16 @@ int host_view(pt_buf *b, std::vector<uint8_t> &tmp, const uint8_t **out) {
     return PT_OK;
 }
 
-// The upload shadow of the triangle buffer is read by the mesh-level re-layout only: once that is
-// done a large one is given back (0.96 GB for 10 M triangles); a later mesh-level re-layout of the
-// same buffer (other node format, instances rooted inside a tree) reads the device copy instead.
-// The BVH and instance buffers keep theirs: moving instances re-lays out the scene level every frame.
-void release_large_shadow(pt_buf *b) {
+// The upload shadows of the triangle and mesh-BVH buffers are read by the mesh-level re-layout only
+// (the scene level works from the root-node copies the mesh level keeps): once the layout stands,
+// large ones are given back (0.96 GB each for 10 M triangles); a later mesh-level re-layout of the
+// same buffers (other node format, instances rooted inside a tree) reads the device copies instead.
+void release_large_shadow(const pt_buf *b) {
     size_t least = (size_t)64 << 20;
     if(const char *e = getenv("RTA_SHADOW_RELEASE_MIN")) least = (size_t)strtoull(e, nullptr, 10);  // (test aid)
     if(b->shadow_valid && b->shadow.size() >= least) {
+        // (the upload that reads the shadow was queued on the context's stream and may still be running)
+        if(hipStreamSynchronize(b->ctx->stream) != hipSuccess) return;
         b->shadow_valid = false;
         std::vector<uint8_t>().swap(b->shadow);
     }
@@ -260,14 +262,17 @@ int prepare_scene(pt_pass *p) {
         }
         p->n_material_floats = n_mat;
         if(scene_changed) {
-            if((rc = host_view(b_mesh, t_mesh, &mesh))) return rc;
             if((rc = host_view(b_scene, t_scene, &scene))) return rc;
             if(b_tris->bytes % sizeof(TriangleRec) || b_mesh->bytes % sizeof(BVHNodeInfo) || b_scene->bytes % sizeof(BVHNodeInfo))
                 return fail(PT_ERR_INVALID, "triangle / BVH buffer sizes are not multiples of 96 / 48 bytes");
-            const BVHNodeInfo *mesh_n = reinterpret_cast<const BVHNodeInfo *>(mesh);
+            // The mesh BVH array is read by the mesh-level re-layout; the scene level needs the instances' root
+            // nodes only, which the mesh level keeps copies of: moving instances does not touch the big array.
+            const BVHNodeInfo *mesh_n = nullptr;
             const size_t n_mesh_nodes = b_mesh->bytes / sizeof(BVHNodeInfo);
             std::string err;
             if(mesh_changed) {
+                if((rc = host_view(b_mesh, t_mesh, &mesh))) return rc;
+                mesh_n = reinterpret_cast<const BVHNodeInfo *>(mesh);
                 if((rc = host_view(b_tris, t_tris, &tris))) return rc;
                 p->mesh_level_valid = false;
                 p->scene_level_valid = false;
@@ -280,9 +285,6 @@ int prepare_scene(pt_pass *p) {
                 p->mesh_level_builds++;
                 slot_mark(p, PT_SLOT_TRIANGLE);
                 slot_mark(p, PT_SLOT_MESH_BVH);
-                tris = nullptr;
-                std::vector<uint8_t>().swap(t_tris);
-                release_large_shadow(b_tris);
             }
             AccelSceneLevel sl;
             bool missing_root = false;
@@ -292,6 +294,10 @@ int prepare_scene(pt_pass *p) {
                 // an instance starts inside a tree: give the mesh level wide trees for those nodes too
                 std::vector<int32_t> roots;
                 for(size_t i = 0; i < n_inst; i++) roots.push_back(ii[i].meshIndex);
+                if(!mesh_n) {
+                    if((rc = host_view(b_mesh, t_mesh, &mesh))) return rc;
+                    mesh_n = reinterpret_cast<const BVHNodeInfo *>(mesh);
+                }
                 if((rc = host_view(b_tris, t_tris, &tris))) return rc;
                 p->mesh_level_valid = false;
                 AccelMeshLevel &ml = p->mesh_level;
@@ -301,7 +307,6 @@ int prepare_scene(pt_pass *p) {
                 std::vector<TNode>().swap(ml.slots);
                 p->mesh_level_valid = true;
                 p->mesh_level_builds++;
-                release_large_shadow(b_tris);
                 ok = build_accel_scene_level(mesh_n, n_mesh_nodes, p->mesh_level, reinterpret_cast<const BVHNodeInfo *>(scene),
                                              b_scene->bytes / sizeof(BVHNodeInfo), ii, n_inst, sl, err);
             }
@@ -309,6 +314,8 @@ int prepare_scene(pt_pass *p) {
                 p->scene_level_valid = false;
                 return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
             }
+            release_large_shadow(b_tris);
+            release_large_shadow(b_mesh);
             {
                 // material types, for the shade launch's grouping; mixed_materials: more than one type is in use
                 bool seen[3] = {false, false, false};
@@ -1238,6 +1245,7 @@ int pt_pass_intersect(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *hits) {
     if(rc) return rc;
     hits->version++;
     hits->shadow_valid = false;
+    release_large_shadow(rays);  // (nothing on the host reads a ray buffer)
     if(n == 0) return PT_OK;
     JOIN_TRY(p->ctx);
     unsigned *cnt = static_cast<unsigned *>(p->d_counters.p);

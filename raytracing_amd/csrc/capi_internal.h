@@ -52,8 +52,10 @@ struct pt_buf {
     pt_ctx *ctx = nullptr;
     void *dptr = nullptr;
     size_t bytes = 0;
-    std::vector<uint8_t> shadow;  // last bytes uploaded from the host, if shadow_valid
-    bool shadow_valid = false;
+    // last bytes uploaded from the host, if shadow_valid: a cache of the device copy for host-side readers
+    // (the traversal re-layout), given back when large once nothing is going to read it
+    mutable std::vector<uint8_t> shadow;
+    mutable bool shadow_valid = false;
     uint64_t version = 0;  // bumped by every content change
     bool owned = true;     // false: a view into memory its owner frees (the outputs of a pass)
 };

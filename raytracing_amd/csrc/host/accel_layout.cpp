@@ -545,6 +545,18 @@ bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const 
         err = "scene too large for 29-bit mesh slots";
         return false;
     }
+    {
+        std::vector<int32_t> ids = roots;
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        out.root_ids.clear();
+        out.root_nodes.clear();
+        for(int32_t r : ids)
+            if(r >= 0 && (size_t)r < n_mesh_nodes) {
+                out.root_ids.push_back(r);
+                out.root_nodes.push_back(mesh[r]);
+            }
+    }
     lap("wide nodes");
     // ---- binary nodes and leaves
     auto mesh_ref = [&](int32_t c) { return make_ref(mesh[c].triangleIndex >= 0 ? REF_TRIANGLE : REF_MESH_INNER, slot_of[c]); };
@@ -606,7 +618,11 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
         err = "mesh level was built for another mesh BVH";
         return false;
     }
-    auto mesh_ref = [&](int32_t c) { return make_ref(mesh[c].triangleIndex >= 0 ? REF_TRIANGLE : REF_MESH_INNER, ml.slot_of[c]); };
+    auto node_at = [&](int32_t c) -> const BVHNodeInfo * {
+        if(mesh) return &mesh[c];
+        auto it = std::lower_bound(ml.root_ids.begin(), ml.root_ids.end(), c);
+        return it != ml.root_ids.end() && *it == c ? &ml.root_nodes[it - ml.root_ids.begin()] : nullptr;
+    };
     // ---- instances
     out.instances.resize(n_inst);
     int max_mesh_height = 1, max_wide_height = 0;
@@ -623,9 +639,15 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
         InstAccel &a = out.instances[i];
         for(int r = 0; r < 3; r++)
             for(int c = 0; c < 4; c++) a.row[r][c] = s.world2local[c * 4 + r];
-        const BVHNodeInfo &root = mesh[s.meshIndex];
+        const BVHNodeInfo *root_p = node_at(s.meshIndex);
+        if(!root_p) {  // (only without the mesh array: not a node the mesh level kept)
+            if(missing_root) *missing_root = true;
+            err = "instance " + std::to_string(i) + " starts at a node that is not a mesh root";
+            return false;
+        }
+        const BVHNodeInfo &root = *root_p;
         set_box(a.root_lo, a.root_hi, root);
-        a.root_ref = mesh_ref(s.meshIndex);
+        a.root_ref = make_ref(root.triangleIndex >= 0 ? REF_TRIANGLE : REF_MESH_INNER, ml.slot_of[s.meshIndex]);
         if(root.triangleIndex >= 0) {
             a.wide_root_ref = a.root_ref;
         } else {

@@ -25,6 +25,10 @@ struct AccelMeshLevel {
     // lets the ordered traversal skip or loosen the tests of ancestors)
     bool nested = true;
     size_t n_tris = 0;
+    // copies of the nodes that have a wide tree (mesh roots and whatever else instances start at), by
+    // ascending node index: all the scene level reads of the mesh BVH, so it can be rebuilt without that array
+    std::vector<int32_t> root_ids;
+    std::vector<BVHNodeInfo> root_nodes;
 };
 
 // Scene level: depends on the instance and scene-BVH buffers (and the mesh roots' boxes).
@@ -41,7 +45,9 @@ struct AccelSceneLevel {
 // Both return false and set err when the buffers are inconsistent.
 // Every node without a parent gets a wide tree; extra_roots names further nodes that instances
 // use as mesh roots.  The scene level sets missing_root (and fails) when an instance names an
-// inner node that has none: the caller rebuilds the mesh level with those roots.
+// inner node that has none: the caller rebuilds the mesh level with those roots.  The scene level may be
+// given mesh == nullptr: it then works from the root copies the mesh level keeps, and reports an instance
+// that starts anywhere else as a missing root.
 // quantise: 0 = WNodes, 1 or -1 (the default choice) = QNodes, which measured faster on small and large scenes alike.
 bool build_accel_mesh_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const TriangleRec *tris, size_t n_tris,
                             const std::vector<int32_t> &extra_roots, int quantise, AccelMeshLevel &out, std::string &err);
