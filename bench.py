@@ -139,7 +139,7 @@ def main():
     ctx = device.Context(local_rank)
     host_build_s = time.time() - t_setup
     # host -> device: the scene arrays and sky textures as the boundary takes them (host pointers),
-    # and the re-layout + upload of the traversal arrays, which the first use of the pass triggers
+    # and the re-layout + upload of the traversal arrays (pt_pass_prepare; the first draw would do it otherwise)
     t_up = time.perf_counter()
     sb = device.SceneBuffers(ctx, sd, sky)
     npix = W * H
@@ -147,12 +147,9 @@ def main():
     p.bind_scene(sb)
     p.set_wide_nodes(args.wide_nodes)
     p.set_material_grouping(args.material_grouping)
-    _r = device.Buffer(ctx, np.array([0, 0, 0, 0, 0, 1], np.float32))
-    _h = device.Buffer(ctx, nbytes=device.HIT_DTYPE.itemsize)
-    p.intersect(_r, 1, _h)
+    p.prepare()
     ctx.synchronize()
     upload_s = time.perf_counter() - t_up
-    _r.release(); _h.release()
     upload_bytes = sum(b.nbytes for b in sb.buffers()) + 2 * sky.rgb.nbytes + sum(t.nbytes for t in sd.textures)
     setup_s = time.time() - t_setup
     setup_done.set()

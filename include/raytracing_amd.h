@@ -205,6 +205,15 @@ int pt_pass_set_traversal(pt_pass *pass, int mode);
  * scene measured),  -1 (default) = the library's choice, currently 1. */
 int pt_pass_set_wide_nodes(pt_pass *pass, int format);
 
+/* Does now what the next draw or intersect would do first: validates the bound scene buffers and
+ * (re)builds what changed -- the traversal arrays from slots 2-5 (host work: about a second per
+ * 10 M triangles on 16 threads, then an upload), the texture descriptor table from slot 0.
+ * Replaces the eager half of ResourceManager::reload_meshes / reload_scene
+ * (src/ResourceManager.cpp:95-224), which upload when the scene changes rather than inside
+ * the frame: a loader calls this after binding, and the first draw then starts at once.
+ * Waits for the draws in flight when something has to be rebuilt. */
+int pt_pass_prepare(pt_pass *pass);
+
 /* How many draws may be in flight on the device at once (1..16, default 3); no counterpart in
  * the reference, whose GL driver queues frames by itself.  pt_pass_draw returns as soon as
  * the draw is queued; consecutive draws run on separate HIP streams with path state of their

@@ -99,6 +99,7 @@ SIGNATURES = {
     "pt_pass_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats), C.c_int]),
     "pt_pass_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_wide_nodes": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_pass_prepare": (C.c_int, [C.c_void_p]),
     "pt_pass_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_tail_threshold": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_set_material_grouping": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1207,6 +1207,12 @@ int pt_pass_set_traversal(pt_pass *pass, int mode) {
     return PT_OK;
 }
 
+int pt_pass_prepare(pt_pass *pass) {
+    if(!pass) return fail(PT_ERR_INVALID, "pt_pass_prepare: null pass");
+    HIP_TRY(hipSetDevice(pass->ctx->device));
+    return prepare_scene(pass);
+}
+
 int pt_pass_set_wide_nodes(pt_pass *pass, int format) {
     if(!pass) return fail(PT_ERR_INVALID, "pt_pass_set_wide_nodes: null pass");
     if(format < -1 || format > 1) return fail(PT_ERR_INVALID, "pt_pass_set_wide_nodes: format must be -1 (by scene size), 0 (full precision) or 1 (quantised)");

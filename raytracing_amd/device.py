@@ -242,6 +242,10 @@ class PathTracingPass:
                     scene_level_builds=int(s.scene_level_builds), debug=[int(x) for x in s.debug],
                     reference_order_forced=int(s.reference_order_forced))
 
+    def prepare(self):
+        """Validates the bound scene buffers and builds the traversal arrays now instead of inside the next draw."""
+        check(lib.pt_pass_prepare(self.h))
+
     def set_traversal(self, mode):
         """0 = ordered traversal with exact fallback (default), 1 = reference order only."""
         check(lib.pt_pass_set_traversal(self.h, int(mode)))

@@ -233,3 +233,25 @@ def test_stack_overflow_is_reported_by_the_calls_that_wait():
     env = dict(os.environ, RAYTRACING_AMD_LIB=lib, RTA_SPILL_DEPTH_CAP="0")
     r = subprocess.run([sys.executable, "-c", _OVERFLOW_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=100)
     assert r.returncode == 0 and "overflow reported" in r.stdout, r.stdout + r.stderr
+
+
+def test_prepare_builds_the_traversal_arrays_ahead_of_the_first_draw(casa, gpu_ctx, small_sky):
+    """pt_pass_prepare does the eager half of ResourceManager::reload_meshes / reload_scene
+    (src/ResourceManager.cpp:95-224): after it, the first draw finds nothing to rebuild; with a slot
+    unbound it reports that instead of the draw."""
+    from raytracing_amd import _capi, device, scene
+    p = device.PathTracingPass(gpu_ctx, 64, 36)
+    with pytest.raises(_capi.PtError, match="not bound"):
+        p.prepare()
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p.bind_scene(sb)
+    p.prepare()
+    st = p.stats()
+    assert st["mesh_level_builds"] == 1 and st["scene_level_builds"] == 1 and st["draws"] == 0
+    p.set_params(scene.make_params(64, 36, scene.casa_camera(), small_sky, spp=1, max_depth=2))
+    p.draw()
+    p.prepare()
+    st = p.stats()
+    assert st["mesh_level_builds"] == 1 and st["scene_level_builds"] == 1 and st["draws"] == 1
+    p.destroy()
+    sb.release()
