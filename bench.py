@@ -147,7 +147,9 @@ def main():
     p.bind_scene(sb)
     p.set_wide_nodes(args.wide_nodes)
     p.set_material_grouping(args.material_grouping)
-    p.prepare()
+    if wl != "casa_isect":
+        p.set_pipeline(args.pipeline)
+    p.prepare()   # (traversal arrays and the path state of every draw in flight: nothing is allocated inside the timed region)
     ctx.synchronize()
     upload_s = time.perf_counter() - t_up
     upload_bytes = sum(b.nbytes for b in sb.buffers()) + 2 * sky.rgb.nbytes + sum(t.nbytes for t in sd.textures)

@@ -1210,7 +1210,14 @@ int pt_pass_set_traversal(pt_pass *pass, int mode) {
 int pt_pass_prepare(pt_pass *pass) {
     if(!pass) return fail(PT_ERR_INVALID, "pt_pass_prepare: null pass");
     HIP_TRY(hipSetDevice(pass->ctx->device));
-    return prepare_scene(pass);
+    int rc = prepare_scene(pass);
+    if(rc) return rc;
+    // the path state of every draw that may be in flight (a draw allocates its lane's at first use otherwise:
+    // eleven device allocations, a millisecond or two inside somebody's frame)
+    const int n_shadow = pass->have_params ? 1 + pass->params.lightCount : 1;
+    for(int k = 0; k < pass->n_lanes; k++)
+        if((rc = prepare_lane(pass, pass->lanes[k], n_shadow))) return rc;
+    return PT_OK;
 }
 
 int pt_pass_set_wide_nodes(pt_pass *pass, int format) {
