@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--textures", type=int, default=0, help="synth_pt: number of procedural RGBA8 albedo maps")
     ap.add_argument("--texture-size", type=int, default=4096)
     ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
-    ap.add_argument("--pipeline", type=int, default=6, help="draws in flight on the device (pt_pass_set_pipeline)")
+    ap.add_argument("--pipeline", type=int, default=10, help="draws in flight on the device (pt_pass_set_pipeline)")
     ap.add_argument("--wide-nodes", type=int, default=-1, choices=[-1, 0, 1],
                     help="node format of the ordered traversal (pt_pass_set_wide_nodes): -1 library default, 0 fp32, 1 quantised")
     ap.add_argument("--hw-queues", type=int, default=16,
