@@ -54,7 +54,7 @@ def parse():
                          "runtime starts, so under rocprofv3 export the variable instead.  Reported in config.")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every rank draws --steps samples (N x steps in all); strong = --steps samples in all, "
-                         "sliced over the ranks (BASELINE config 4: a fixed 256-spp frame cut over 2/4/8 GPUs)")
+                         "sliced over the ranks (the multi-GPU benchmark configuration: a fixed 256-spp frame cut over 2/4/8 GPUs)")
     ap.add_argument("--collective", default="capi", choices=["capi", "torch"],
                     help="N > 1: combine through the library's own pt_pass_allreduce (RCCL, default) or through torch.distributed")
     ap.add_argument("--material-grouping", type=int, default=-1, choices=[-1, 0, 1],

@@ -1,4 +1,4 @@
-"""Full-size checks (the sizes BASELINE.json names) through properties that need no oracle run:
+"""Full-size checks (the sizes of the benchmark configurations) through properties that need no oracle run:
 the ordered traversal and the reference-order traversal are two independent kernels and must
 return the same hits for all 16 Mi rays of the intersection microbench, and the same seven
 images for a 1920x1080 depth-8 frame, whatever the number of draws in flight; a bounded sample

@@ -1,6 +1,6 @@
 """The large configurations on a real device: a 2 M-triangle scene with rough dielectrics, RGBA8
-albedo maps and MAX_DEPTH 16 against the oracle bit for bit (the shape of BASELINE config 5), and a
-10 M-triangle scene at 3840x2160, MAX_DEPTH 8 (BASELINE config 4's frame) through the property that
+albedo maps and MAX_DEPTH 16 against the oracle bit for bit (the shape of the largest benchmark configuration), and a
+10 M-triangle scene at 3840x2160, MAX_DEPTH 8 (the frame of the multi-GPU benchmark configuration) through the property that
 needs no oracle run at that size: the ordered traversal and the reference-order traversal, two
 independent kernels over two node formats, must produce the same seven images.  Both also check
 that no ray ran out of traversal stack (spill depth is sized from these deeper trees) and that
