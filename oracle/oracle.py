@@ -291,6 +291,27 @@ def ref_intersect(scene_data, rays):
     return np.frombuffer(raw, np.dtype([("instance", "<i4"), ("triangle", "<i4"), ("t", "<f4")]), len(rays)).copy()
 
 
+def ref_scene_level(scene_data):
+    """The reference's scene level for the instances of scene_data (ResourceManager::reload_scene,
+    reload_sceneBVH, reload_instances run over its own AABB / glm / BVHNode::build): returns
+    (scene nodes as uint8 array of 48-byte records, world2local (n_inst, 16), siz, depth)."""
+    n_inst = len(scene_data.instances)
+    with tempfile.TemporaryDirectory() as d:
+        _write_meshes(d + "/m.bin", scene_data)
+        with open(d + "/s.bin", "wb") as f:
+            f.write(struct.pack("<i", n_inst))
+            for i in range(n_inst):
+                f.write(np.ascontiguousarray(scene_data.l2w[i], np.float32).tobytes())
+                f.write(struct.pack("<i", int(scene_data.mesh_index[i])))
+        subprocess.check_call([REF_HARNESS, "scene", d + "/m.bin", d + "/s.bin", d + "/o.bin"])
+        raw = open(d + "/o.bin", "rb").read()
+    n, = struct.unpack_from("<i", raw, 0)
+    nodes = np.frombuffer(raw, np.uint8, n * 48, 4).copy()
+    w2l = np.frombuffer(raw, np.float32, n_inst * 16, 4 + n * 48).reshape(n_inst, 16).copy()
+    siz, depth = struct.unpack_from("<2i", raw, 4 + n * 48 + n_inst * 64)
+    return nodes, w2l, siz, depth
+
+
 def ref_mat_inverse(mats):
     mats = np.ascontiguousarray(mats, np.float32).reshape(-1, 16)
     with tempfile.TemporaryDirectory() as d:

@@ -13,6 +13,9 @@
 // compiled headless:
 //   - Mesh::build_meshBVH            (src/instance/Mesh.cpp:10-22)
 //   - ResourceManager::reload_meshes (src/ResourceManager.cpp:116-140, BFS flatten)
+//   - ResourceManager::reload_scene / reload_sceneBVH / reload_instances
+//     (src/ResourceManager.cpp:146-224: world boxes from eight transformed corners,
+//     BFS flatten of the scene tree, world2local = glm::inverse)
 //
 // File protocol (little endian, tightly packed):
 //   meshes file : i32 nmesh ; per mesh { i32 ntri ; f32 pos[ntri*9] }
@@ -21,13 +24,18 @@
 //   scene file  : i32 ninst ; per inst { f32 l2w[16] (column major) ; i32 mesh }
 //   rays file   : i32 nrays ; f32 ray[nrays*6] (ox oy oz dx dy dz)
 //   hits out    : per ray { i32 inst ; i32 tri (global) ; f32 t }   (-1,-1,1e18 = miss)
+//   scene out   : i32 nnodes ; node[nnodes] (as above, inst = instance index at leaves) ;
+//                 per inst { f32 world2local[16] } ; i32 siz ; i32 depth
 #include "BVH.h"
+#include "instance/Instance.h"
+#include "instance/Mesh.h"
 #include "hdrloader.h"
 #include "stb_image.h"
 #include "glm/glm.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <queue>
 #include <map>
 #include <string>
@@ -161,6 +169,76 @@ static int cmd_isect(const char *meshes, const char *scene, const char *rays, co
     return 0;
 }
 
+// Scene level: the statements of ResourceManager::reload_scene (src/ResourceManager.cpp:200-221) over the
+// reference's own AABB, glm and BVHNode::build, then the flatten of reload_sceneBVH (:166-198) and the
+// world2local of reload_instances (:154).  BVHNode::build reads instancePtr->mesh->meshBVHRoot of a
+// one-primitive node (src/BVH.cpp:19-24) and nothing else of either object; neither can be constructed
+// headless (their constructors live in GL-entangled translation units), so both are zeroed storage of the
+// reference's own class layouts (instance/Instance.h, instance/Mesh.h) with those two members set.
+static int cmd_scene(const char *meshes, const char *scene, const char *out) {
+    MeshSet ms; load_meshes(meshes, ms);
+    std::vector<char> sb = slurp(scene);
+    const char *p = sb.data();
+    int ninst; memcpy(&ninst, p, 4); p += 4;
+    std::vector<glm::mat4> mats(ninst); std::vector<int> meshOf(ninst);
+    std::vector<BVHPrimitive> primitives;
+    std::map<Instance*, int> instanceIndex;
+    for(int k = 0; k < ninst; k++) {
+        memcpy(&mats[k][0][0], p, 64); p += 64;
+        memcpy(&meshOf[k], p, 4); p += 4;
+        const glm::mat4 &mat = mats[k];
+        BVHPrimitive prim;
+        Mesh *mesh = static_cast<Mesh*>(calloc(1, sizeof(Mesh)));
+        mesh->meshBVHRoot = ms.roots[meshOf[k]];
+        Instance *ins = static_cast<Instance*>(calloc(1, sizeof(Instance)));
+        ins->mesh = mesh;
+        instanceIndex[ins] = k;
+        prim.instancePtr = ins;
+        AABB cube = ms.roots[meshOf[k]]->aabb;
+        for(int i = 0;i < 8;i++) {
+            vec3 point = {
+                    (i & 1) ? cube.mi[0] : cube.mx[0],
+                    (i & 2) ? cube.mi[1] : cube.mx[1],
+                    (i & 4) ? cube.mi[2] : cube.mx[2]
+            };
+            point = mat * vec4(point, 1);
+            prim.aabb.addPoint(point);
+        }
+        primitives.push_back(prim);
+    }
+    BVHNode *root = BVHNode::build(primitives);   // reference code
+    std::vector<FlatNode> flat;
+    std::queue<BVHNode*> q;
+    q.emplace(root);
+    int N = 0;
+    while(!q.empty()) {
+        BVHNode *n = q.front(); q.pop();
+        FlatNode y;
+        y.aa[0] = n->aabb.mi.x; y.aa[1] = n->aabb.mi.y; y.aa[2] = n->aabb.mi.z; y.aa[3] = 0;
+        y.bb[0] = n->aabb.mx.x; y.bb[1] = n->aabb.mx.y; y.bb[2] = n->aabb.mx.z; y.bb[3] = 0;
+        y.ls = -1; y.rs = -1; y.inst = -1; y.tri = -1;   // BVHNodeInfo's defaults, src/ResourceManager.h
+        if(n->instancePtr) {
+            y.inst = instanceIndex[n->instancePtr];
+            flat.push_back(y);
+            continue;
+        }
+        if(n->ls) y.ls = ++N, q.emplace(n->ls);
+        if(n->rs) y.rs = ++N, q.emplace(n->rs);
+        flat.push_back(y);
+    }
+    FILE *f = fopen(out, "wb");
+    int n = (int)flat.size();
+    fwrite(&n, 4, 1, f);
+    fwrite(flat.data(), sizeof(FlatNode), flat.size(), f);
+    for(int k = 0; k < ninst; k++) {
+        glm::mat4 w2l = glm::inverse(mats[k]);
+        fwrite(&w2l[0][0], 4, 16, f);
+    }
+    fwrite(&root->siz, 4, 1, f); fwrite(&root->depth, 4, 1, f);
+    fclose(f);
+    return 0;
+}
+
 // glm::inverse / glm mat4*mat4 as compiled from the vendored headers.
 //   in : i32 n ; f32 m[n*16]      out: f32 inv[n*16] ; f32 prod[16] (m0*m1*...*m(n-1))
 static int cmd_mat(const char *in, const char *out) {
@@ -216,10 +294,11 @@ int main(int argc, char **argv) {
     std::string c = argc > 1 ? argv[1] : "";
     if(c == "bvh" && argc == 4) return cmd_bvh(argv[2], argv[3]);
     if(c == "isect" && argc == 6) return cmd_isect(argv[2], argv[3], argv[4], argv[5]);
+    if(c == "scene" && argc == 5) return cmd_scene(argv[2], argv[3], argv[4]);
     if(c == "mat" && argc == 4) return cmd_mat(argv[2], argv[3]);
     if(c == "hdr" && argc == 3) return cmd_hdr(argv[2]);
     if(c == "stb" && argc == 4) return cmd_stb(argv[2], argv[3]);
-    fprintf(stderr, "usage: ref_harness bvh <meshes> <out> | isect <meshes> <scene> <rays> <out> | "
+    fprintf(stderr, "usage: ref_harness bvh <meshes> <out> | isect <meshes> <scene> <rays> <out> | scene <meshes> <scene> <out> | "
                     "mat <in> <out> | hdr <out> | stb <image> <out>\n");
     return 2;
 }

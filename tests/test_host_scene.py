@@ -106,6 +106,54 @@ def test_one_large_mesh_builds_the_same_tree_on_any_number_of_threads(oracle_mod
         assert np.array_equal(siz, one.mesh_siz) and np.array_equal(depth, one.mesh_depth)
 
 
+def _scene_with_instances(tri_count, triangles, l2w, mesh_index):
+    from raytracing_amd import scene
+    b = scene.SceneBuilder()
+    base = 0
+    for n in tri_count:
+        b.add_mesh(triangles[base:base + n])
+        base += int(n)
+    for m, mat in zip(mesh_index, l2w):
+        b.add_instance(int(m), mat)
+    return b.finish(2)
+
+
+def _w2l_bits(sd):
+    return np.ascontiguousarray(sd.instances["w2l"]).reshape(-1, 16).view(np.uint32)
+
+
+def test_scene_level_bit_exact_with_the_reference(casa):
+    """ResourceManager::reload_scene / reload_sceneBVH / reload_instances (src/ResourceManager.cpp:146-224)
+    as the reference's own compiled code produces them (tests/golden/make_scene_level.py): scene BVH nodes,
+    node count, depth and world2local of casa, and of 47 awkward instances -- rotated, mirrored, scaled,
+    sharing meshes, exact duplicates whose equal centres leave the tree to std::sort's tie order."""
+    f = np.load(os.path.join(GOLDEN, "scene_level.npz"))
+    assert np.array_equal(np.frombuffer(casa.scene_nodes.tobytes(), np.uint8), f["casa_nodes"])
+    assert np.array_equal(_w2l_bits(casa), f["casa_w2l"].view(np.uint32))
+    assert [casa.bvh_siz, casa.bvh_depth] == list(f["casa_siz_depth"])
+    g = np.load(os.path.join(GOLDEN, "synth_meshes.npz"))
+    sd = _scene_with_instances(g["tri_count"], g["triangles"], f["awk_l2w"], f["awk_mesh_index"])
+    assert np.array_equal(np.frombuffer(sd.scene_nodes.tobytes(), np.uint8), f["awk_nodes"])
+    assert np.array_equal(_w2l_bits(sd), f["awk_w2l"].view(np.uint32))
+    assert [sd.bvh_siz, sd.bvh_depth] == list(f["awk_siz_depth"])
+
+
+def test_scene_level_live_against_compiled_reference(oracle_mod):
+    if not oracle_mod.have_ref():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    from raytracing_amd import scene
+    rng = np.random.default_rng(9)
+    g = np.load(os.path.join(GOLDEN, "synth_meshes.npz"))
+    for n_inst in (1, 2, 3, 60):
+        l2w = np.array([scene.transform_matrix(tuple(rng.normal(0, 4, 3)), tuple(rng.uniform(0, 360, 3)), tuple(rng.uniform(0.2, 3, 3)))
+                        for _ in range(n_inst)], np.float32).reshape(-1, 16)
+        mesh_index = rng.integers(0, len(g["tri_count"]), n_inst)
+        sd = _scene_with_instances(g["tri_count"], g["triangles"], l2w, mesh_index)
+        nodes, w2l, siz, depth = oracle_mod.ref_scene_level(sd)
+        assert np.array_equal(np.frombuffer(sd.scene_nodes.tobytes(), np.uint8), nodes), n_inst
+        assert np.array_equal(_w2l_bits(sd), w2l.view(np.uint32)) and [sd.bvh_siz, sd.bvh_depth] == [siz, depth]
+
+
 def test_glm_inverse_and_product_bit_exact():
     from raytracing_amd import scene
     g = np.load(os.path.join(GOLDEN, "glm_mat.npz"))
