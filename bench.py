@@ -57,6 +57,9 @@ def parse():
                          "sliced over the ranks (the multi-GPU benchmark configuration: a fixed 256-spp frame cut over 2/4/8 GPUs)")
     ap.add_argument("--collective", default="capi", choices=["capi", "torch"],
                     help="N > 1: combine through the library's own pt_pass_allreduce (RCCL, default) or through torch.distributed")
+    ap.add_argument("--tail", type=int, default=-1,
+                    help="pt_pass_set_tail_threshold for the timed region: -1 the library's choice, 0 no tail launch (the counter "
+                         "passes of tools/run_pmc.sh use --pipeline 1 --tail 0: the launches the roofline leg times)")
     ap.add_argument("--material-grouping", type=int, default=-1, choices=[-1, 0, 1],
                     help="pt_pass_set_material_grouping: -1 the library's choice (default: off), 0 off, 1 on")
     ap.add_argument("--rehearse", action="store_true",
@@ -147,6 +150,7 @@ def main():
     p.bind_scene(sb)
     p.set_wide_nodes(args.wide_nodes)
     p.set_material_grouping(args.material_grouping)
+    p.set_tail_threshold(args.tail)
     if wl != "casa_isect":
         p.set_pipeline(args.pipeline)
     p.prepare()   # (traversal arrays and the path state of every draw in flight: nothing is allocated inside the timed region)
@@ -282,7 +286,7 @@ def main():
             prof = p.profile()
             pst = p.stats(reset=True)
             p.set_profiling(False)
-            p.set_tail_threshold(-1)
+            p.set_tail_threshold(args.tail)
             p.set_pipeline(args.pipeline)
             note("per-kernel profiling pass done")
             prof["draws"] = n_prof

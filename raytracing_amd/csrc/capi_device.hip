@@ -399,7 +399,11 @@ int prepare_scene(pt_pass *p) {
 // +12 % (casa, 6 draws in flight) and +3 % (10 M triangles) over full grids.
 void set_draw_grid(pt_pass *p) {
     const char *e = getenv("RTA_DRAW_BLOCKS_PER_CU");  // (tuning aid)
-    const int shared = e && atoi(e) > 0 && atoi(e) <= 8 ? atoi(e) : 3;
+    // (blocks per CU of a traversal launch that shares the device with other draws.  Measured, casa 1080p / 10 M
+    // triangles at 4K, Mrays/s with 1 | 2 | 3 blocks: 3 draws in flight 2064 | 2482 | 2472; 6: 2792 | 2826 | 2780 and
+    // 1809 | 1835 | 1876; 10: 2990 | 2932 | 2891 and 1888 | 1908 | 1881; 14: 3014 | 2974 | 2910 -- the more draws
+    // share the device, the smaller each one's persistent grid should be)
+    const int shared = e && atoi(e) > 0 && atoi(e) <= 8 ? atoi(e) : (p->n_lanes >= 8 ? 1 : 3);
     p->draw_blocks = p->ctx->num_cus * (p->n_lanes > 1 ? shared : 8);
 }
 

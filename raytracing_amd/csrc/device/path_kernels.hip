@@ -16,8 +16,10 @@
 namespace rta {
 namespace {
 
+// (128 threads per block measured 1.5 % (casa) and 0.6 % (10 M triangles) faster than 256 with ten draws in flight,
+// 64 the same as 128, 512 12 % slower: small blocks find room next to the persistent traversal grids sooner)
 #ifndef RT_SHADE_BLOCK
-#define RT_SHADE_BLOCK 256
+#define RT_SHADE_BLOCK 128
 #endif
 constexpr int SHADE_BLOCK = RT_SHADE_BLOCK;
 

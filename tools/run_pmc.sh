@@ -2,6 +2,9 @@
 # Collects rocprofv3 PMC counters for one bench workload, one pass per counter group
 # (rocprofv3 does not split counters over passes).  Usage on the GPU box:
 #   tools/run_pmc.sh <outdir> <bench args...>
+# For the path-tracing workloads pass --pipeline 1 --tail 0: draws one at a time, every vertex in launches of its
+# own, which is what bench.py's roofline leg times (the profiler serialises kernels anyway; what matters is that
+# the launches have the grids and the rays of the ones the launch time is taken from).
 set -u
 out=$1; shift
 mkdir -p "$out"
