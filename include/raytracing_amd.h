@@ -138,17 +138,24 @@ enum {
 int pt_pass_bind(pt_pass *pass, int slot, pt_buf *buf);
 /* RenderPass::bind_texture(name, ...), RenderPass.cpp:123-128.  Names understood:
  * "skybox", "skybox_samplecache" (main.cpp:179-180; 3-channel float), and the four images of
- * the raster pass, read only when pt_params.RasterizaionFor1st is set (main.cpp:181-184,
- * RasterPass.cpp:100-133; float textures of WINDOW_W x WINDOW_H, row 0 = bottom row):
+ * the raster pass (main.cpp:181-184, RasterPass.cpp:100-133; float textures of
+ * WINDOW_W x WINDOW_H, row 0 = bottom row):
  *   "depthGBufferTexture"          1 channel: distance from the camera along the primary ray
  *                                  (raster_ps.glsl:22), 1e6 where nothing was drawn
  *   "normalGBufferTexture"         3 channels: world-space normal, any length
  *   "uvGBufferTexture"             2 channels
  *   "instanceIndexGBufferTexture"  1 channel: index into the instance buffer (sampled NEAREST,
  *                                  the others LINEAR, as RasterPass sets them up)
- * In that mode no primary ray is traced: the first path vertex is rebuilt from the images
- * (pathtracing.glsl:606-624).  A pixel whose instance index names no instance counts as
- * not covered (an out-of-bounds read in the reference). */
+ * With pt_params.RasterizaionFor1st set, all four are required and no primary ray is traced:
+ * the first path vertex is rebuilt from the images (pathtracing.glsl:606-624); a pixel whose
+ * instance index names no instance counts as not covered (an out-of-bounds read in the
+ * reference).  With RasterizaionFor1st off the first hit is traced, and -- as in the reference,
+ * which samples these two images either way (:615-616) -- when "depthGBufferTexture" and
+ * "instanceIndexGBufferTexture" are bound the depth output is the raster depth (:684) and the
+ * albedo is looked up through the raster instance index (:641; an index that names no instance
+ * falls back to the traced one).  With neither bound (a host without a raster pass) the depth
+ * output is the traced distance, 1e6 on a miss, and the albedo that of the traced instance.
+ * Pass NULL to unbind a name. */
 int pt_pass_bind_texture(pt_pass *pass, const char *name, pt_tex *tex);
 int pt_pass_set_params(pt_pass *pass, const pt_params *params);
 /* Renderer::draw(), Renderer.cpp:30-54: one sample per pixel for the whole frame. */

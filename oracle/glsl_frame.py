@@ -136,7 +136,19 @@ CASES = {
     # dielectric path draws 5 numbers per bounce, so the fourth bounce would reach Sobol dimension 20, which the
     # reference reads out of bounds (sobol_matrix.glsl:25) -- nothing defined to compare with there
     "synth": ("synth", 112, 63, 3, 1, {}),
+    # raster images that DISAGREE with the traced hit (depth scaled and shifted, instance index rotated by three):
+    # with RasterizaionFor1st off the shader still writes the raster depth and looks the albedo up through the
+    # raster instance index (pathtracing.glsl:615-616, :641, :684)
+    "raster": ("casa", 96, 54, 2, 1, {}),
 }
+PERTURBED = ("raster",)
+
+
+def perturb(depth, inst, n_inst):
+    hit = depth <= 100000.0
+    d = np.where(hit, depth * np.float32(1.25) + np.float32(0.5), depth).astype(np.float32)
+    i = ((inst.astype(np.int64) + 3) % n_inst).astype(np.float32)
+    return d, i
 
 
 def case_scene(kind):
@@ -165,8 +177,11 @@ def main():
             # what the raster pass would have drawn for this sample: the primary hit of every pixel (the oracle's
             # closest hits are pinned bit for bit by the compiled reference, tests/golden/casa_rays.npz)
             prim, _ = osc.render(scene.make_params(w, h, camera, sky, spp=1, frame=1, jitter=jit[s - 1], max_depth=0))
-            gbufs.append((prim["depth"].reshape(h, w, 1), prim["normal"].reshape(h, w, 3), np.zeros((h, w, 2), np.float32),
-                          prim["instanceIndex"].reshape(h, w, 1)))
+            g_depth, g_inst = prim["depth"].reshape(h, w, 1), prim["instanceIndex"].reshape(h, w, 1)
+            if tag in PERTURBED:
+                g_depth, g_inst = perturb(g_depth, g_inst, len(sd.instances))
+                out["%s_gbuf_depth" % tag], out["%s_gbuf_inst" % tag] = g_depth, g_inst
+            gbufs.append((g_depth, prim["normal"].reshape(h, w, 3), np.zeros((h, w, 2), np.float32), g_inst))
         prm = scene.make_params(w, h, camera, sky, spp=1, frame=1, jitter=jit[0], max_depth=max_depth, light_count=len(sd.lights), **switches)
         for kind2, exe in exes.items():
             res = run(exe, sd, sky, prm, jit, gbufs, workdir)

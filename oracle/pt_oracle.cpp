@@ -727,10 +727,23 @@ struct Ctx {
         } else {
             cnt.rays_extend++;
             first_isect = intersect_sceneBVH(ray);  // :626-628
-            // the reference keeps the raster depth / instance index here (:615-616, :684); without a
-            // raster pass they are those of the traced hit
+            // The reference keeps the RASTER depth and instance index here (:615-616): the depth output is the
+            // raster depth (:684) and the albedo is looked up through the raster instance index (:641), while
+            // everything else comes from the traced hit.  With the two raster images bound that is reproduced;
+            // without a raster pass both are those of the traced hit (1e6 on a miss = the raster clear value).
             depth = first_isect.exist ? first_isect.t : 1000000.0f;
             instanceIndex = first_isect.instanceIndex;
+            if(sc->depthGBufferTexture.data && sc->instanceIndexGBufferTexture.data) {
+                float suv_x0 = ((float)px + 0.5f) / (float)W, suv_y0 = ((float)py + 0.5f) / (float)H;
+                float wu = suv_x0 * (float)W / (float)pm->WINDOW_W;
+                float wv = (suv_y0 - 1.0f) * (float)H / (float)pm->WINDOW_H + 1.0f;
+                float c[4];
+                texture(sc->depthGBufferTexture, wu, wv, c);
+                depth = c[0];
+                const int raster_index = float_to_int(texture_nearest(sc->instanceIndexGBufferTexture, wu, wv) + 0.01f);
+                // (an index that names no instance is an out-of-bounds read in the reference: the traced one stands in)
+                if(raster_index >= 0 && raster_index < sc->n_instances) instanceIndex = raster_index;
+            }
         }
 
         vec3 resultDI, resultGI, albedo;

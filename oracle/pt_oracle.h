@@ -34,9 +34,12 @@
  *     dimension d uses table row 1 + (d - 1) % 19 with the index replaced by
  *     wang_hash(index + 0x9E3779B9 * ((d - 1) / 19)); rows 1..19 are untouched, so every
  *     draw the reference defines is reproduced bit for bit;
- *   - the raster G-buffer inputs of the reference (depth / instanceIndex textures drawn
- *     by RasterPass) do not exist here: `depth` is the primary hit's t (1e6 on a miss,
- *     the raster clear value) and the albedo lookup uses the traced primary hit.
+ *   - with RasterizaionFor1st off the reference still writes the RASTER depth and looks the
+ *     albedo up through the RASTER instance index (pathtracing.glsl:615-616, :641, :684).  When
+ *     the depth and instance-index images are given, that is reproduced (an index that names
+ *     no instance, an out-of-bounds read there, falls back to the traced one); when they are
+ *     not (no raster pass), `depth` is the primary hit's t (1e6 on a miss, the raster clear
+ *     value) and the albedo lookup uses the traced primary hit.
  */
 #ifndef PT_ORACLE_H
 #define PT_ORACLE_H

@@ -1009,6 +1009,11 @@ int pt_pass_draw(pt_pass *p) {
         dp.gb_normal = desc_of(p->gb_normal);
         dp.gb_uv = desc_of(p->gb_uv);
         dp.gb_inst = desc_of(p->gb_inst);
+    } else if(p->gb_depth && p->gb_inst) {
+        // the reference reads these two even when it traces the first hit (shader/pathtracing.glsl:615-616)
+        dp.gb_depth = desc_of(p->gb_depth);
+        dp.gb_inst = desc_of(p->gb_inst);
+        dp.raster_outputs = 1;
     }
     dp.n_instances = (int)p->scene_level.header.n_instances;
     dp.rays = static_cast<PathRay *>(L.rays.p);

@@ -37,6 +37,9 @@ struct DrawParams {
     TexDesc sky, sky_cache;
     // RasterizaionFor1st: the raster pass's images (distance, world normal, uv, instance index)
     TexDesc gb_depth, gb_normal, gb_uv, gb_inst;
+    // RasterizaionFor1st off, but the depth and instance-index images are bound: the depth output and the albedo
+    // lookup of vertex 0 go through them, as in the reference (gb_depth and gb_inst are valid then)
+    int raster_outputs;
     int n_instances;
     // path state, one slot per pixel
     PathRay *rays;

@@ -54,14 +54,14 @@ __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
     }
 }
 
-// RASTER_FIRST: the instance launched for vertex 0 when the first hit comes from the raster images;
-// kept apart so that the common instance carries none of its registers.
+// RASTER (see shade_vertex): 1 and 2 are the instances launched for vertex 0 when the raster pass's images are in
+// play; kept apart so that the common instance carries none of their registers.
 // Four waves per SIMD (128 registers, a few of them spilled) hide the latency of the gathers
 // better than the three the kernel would get unconstrained (145 registers); five spill too much.
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 4
 #endif
-template <bool RASTER_FIRST, bool GROUP>
+template <int RASTER, bool GROUP>
 __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES, SHADE_WAVES))) void shade_kernel(DrawParams dp, int dep, const unsigned *queue_in,
                                                             const unsigned *count_in, unsigned *queue_out,
                                                             unsigned *count_out, unsigned *shadow_queue,
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
 
     if(blockIdx.x == 0 && threadIdx.x == 0) {
         // (with RasterizaionFor1st the first vertex comes from images: no rays were traced for it)
-        if(!RASTER_FIRST) atomicAdd(&dp.stats[1], dep == 0 ? (unsigned long long)dp.W * (unsigned long long)dp.H : (unsigned long long)n);
+        if(RASTER != 1) atomicAdd(&dp.stats[1], dep == 0 ? (unsigned long long)dp.W * (unsigned long long)dp.H : (unsigned long long)n);
         if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
     }
 
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
             // within each group; which lane shades a path changes nothing about what is computed for it.
             bool back = false;
             if(mine) {
-                const int inst = RASTER_FIRST ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[1].x);
-                const int tri = RASTER_FIRST ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[0].w);
+                const int inst = RASTER == 1 ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[1].x);
+                const int tri = RASTER == 1 ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[0].w);
                 if(tri >= 0 && inst >= 0 && inst < dp.n_instances) back = dp.inst[inst].material_type == 2u;
             }
             const unsigned wave = threadIdx.x >> 6;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
         }
         if(!mine) continue;
         bool continues, has_shadow;
-        shade_vertex<RASTER_FIRST>(dp, dep, i, s_V, continues, has_shadow);
+        shade_vertex<RASTER>(dp, dep, i, s_V, continues, has_shadow);
         // paths that end simply are not appended (queue compaction)
         if(has_shadow) {
             const unsigned pos = atomicAdd(shadow_count, 1u);
@@ -228,11 +228,13 @@ void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *
                   unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group_by_material) {
     const dim3 grid(shade_grid(dp.npix)), block(SHADE_BLOCK);
     if(dep == 0 && dp.p.RasterizaionFor1st != 0)
-        hipLaunchKernelGGL((shade_kernel<true, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
+        hipLaunchKernelGGL((shade_kernel<1, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
+    else if(dep == 0 && dp.raster_outputs)
+        hipLaunchKernelGGL((shade_kernel<2, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
     else if(group_by_material)
-        hipLaunchKernelGGL((shade_kernel<false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
+        hipLaunchKernelGGL((shade_kernel<0, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
     else
-        hipLaunchKernelGGL((shade_kernel<false, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
+        hipLaunchKernelGGL((shade_kernel<0, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count);
 }
 
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,

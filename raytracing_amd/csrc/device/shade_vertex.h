@@ -49,7 +49,12 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 // or, RASTER_FIRST, the raster images).  continues: the path goes on with the ray now in
 // dp.rays[i]; has_shadow: dp.shadow[..][i] holds light samples whose occlusion rays are due.
 // s_T: the Sobol nibble table in LDS (load_sobol_to_lds).
-template <bool RASTER_FIRST>
+// RASTER: what the raster pass's images are used for at vertex 0 (shader/pathtracing.glsl:612-628, :641, :684)
+//   0  nothing (no raster pass behind this host: depth and albedo come from the traced hit);
+//   1  RasterizaionFor1st: they ARE the first hit, no primary ray was traced;
+//   2  RasterizaionFor1st off with the depth and instance-index images bound: the first hit is traced, but the
+//      depth output is the raster depth and the albedo is looked up through the raster instance index, as there.
+template <int RASTER>
 __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsigned i, const unsigned *s_T, bool &continues,
                                              bool &has_shadow) {
     continues = false;
@@ -66,7 +71,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     const float prev_cos = r0.w;  // |wo.z| of the BSDF sample this ray follows
     // RasterizaionFor1st: the first hit comes from the raster pass's images (:606-624), no
     // primary ray was traced
-    const bool raster0 = RASTER_FIRST;
+    const bool raster0 = RASTER == 1;
     float hit_t, hit_u = 0.0f, hit_v = 0.0f;
     int hit_tri = -1, hit_inst;
     bool exist;
@@ -113,6 +118,16 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
 
     PathAccum *acc = dp.acc + i;
 
+    float raster_depth = 0.0f;
+    int raster_inst = -1;
+    if(RASTER == 2 && dep == 0) {
+        const float suv_x0 = ((float)px + 0.5f) / (float)dp.W, suv_y0 = ((float)py + 0.5f) / (float)dp.H;
+        const float wu = suv_x0 * (float)dp.W / (float)P.WINDOW_W;
+        const float wv = (suv_y0 - 1.0f) * (float)dp.H / (float)P.WINDOW_H + 1.0f;
+        raster_depth = texture_rgb(dp.gb_depth, wu, wv).x;
+        raster_inst = float_to_int(texture_nearest_r(dp.gb_inst, wu, wv) + 0.01f);
+    }
+
     if(dep == 0) {
         if(!exist) {
             // :496-499 and the G-buffer writes of :672-688 for a miss
@@ -130,7 +145,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
             const float suv_x = ((float)px + 0.5f) / (float)dp.W, suv_y = ((float)py + 0.5f) / (float)dp.H;
             dp.o_motion[pix * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
             dp.o_motion[pix * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
-            dp.o_depth[pix] = raster0 ? hit_t : 1000000.0f;
+            dp.o_depth[pix] = raster0 ? hit_t : (RASTER == 2 ? raster_depth : 1000000.0f);
             dp.o_normal[pix * 3] = g_normal.x;
             dp.o_normal[pix * 3 + 1] = g_normal.y;
             dp.o_normal[pix * 3 + 2] = g_normal.z;
@@ -182,7 +197,17 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         // first-hit outputs, :640-655 and :682-688
         BSDFQueryRecord ab;
         ab.wi = v3(0.0f); ab.wo = v3(0.0f); ab.mptr = materialPtr; ab.uvx = uvx; ab.uvy = uvy; ab.eta = 1.0f;
-        const V3 albedo = cx.albedo_material(ab);
+        V3 albedo;
+        if(RASTER == 2 && raster_inst >= 0 && raster_inst < dp.n_instances && raster_inst != hit_inst) {
+            // :641 indexes the instance records with the RASTER index (one that names no instance is out of
+            // bounds there; the traced one stands in)
+            ab.mptr = __float_as_int(reinterpret_cast<const float4 *>(dp.inst + raster_inst)[3].y);
+            cx.bind_material(ab.mptr, uvx, uvy);
+            albedo = cx.albedo_material(ab);
+            cx.bind_material(materialPtr, uvx, uvy);
+        } else {
+            albedo = cx.albedo_material(ab);
+        }
         acc->albedo[0] = albedo.x;
         acc->albedo[1] = albedo.y;
         acc->albedo[2] = albedo.z;
@@ -194,7 +219,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         const float suv_x = ((float)px + 0.5f) / (float)dp.W, suv_y = ((float)py + 0.5f) / (float)dp.H;
         dp.o_motion[pix * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
         dp.o_motion[pix * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
-        dp.o_depth[pix] = hit_t;
+        dp.o_depth[pix] = RASTER == 2 ? raster_depth : hit_t;
         dp.o_normal[pix * 3] = normal.x;
         dp.o_normal[pix * 3 + 1] = normal.y;
         dp.o_normal[pix * 3 + 2] = normal.z;

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastS
         const unsigned slot = alive ? queue_in[base + lane] : 0u;
         for(int dep = dep0;; dep++) {
             bool continues = false, has_shadow = false;
-            if(alive) shade_vertex<false>(dp, dep, slot, s_T, continues, has_shadow);
+            if(alive) shade_vertex<0>(dp, dep, slot, s_T, continues, has_shadow);
             alive = continues;
             const unsigned long long m_c = __ballot(continues), m_s = __ballot(has_shadow);
             if((m_c | m_s) == 0ull) break;  // (at MAX_DEPTH shade_vertex lets no path continue)

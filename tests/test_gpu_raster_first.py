@@ -119,3 +119,54 @@ def test_raster_first_needs_its_textures(gpu_ctx, casa, small_sky):
     p.bind_texture("normalGBufferTexture", t3)
     p.destroy()
     sb.release()
+
+
+def test_raster_images_with_rasterization_off(gpu_ctx, oracle_mod, casa, small_sky):
+    """RasterizaionFor1st off: the shader traces the first hit but still writes the RASTER depth and looks the albedo
+    up through the RASTER instance index (shader/pathtracing.glsl:615-616, :641, :684).  With those two images bound
+    the pass does the same -- here with images that disagree with the traced hit: depth scaled and shifted, indices
+    rotated, some naming no instance (out of bounds in the reference; the traced index stands in), a window larger
+    than the frame -- over two samples and with the tail launch and draws in flight in play; the oracle, which
+    tests/test_oracle.py pins on this very behaviour against the reference's shader run as C++, is the judge."""
+    from raytracing_amd import device, scene
+    w, h = 160, 90
+    osc = oracle_mod.OracleScene(casa, small_sky)
+    prim, _ = osc.render(scene.make_params(w, h, scene.casa_camera(), small_sky, max_depth=0))
+    depth = prim["depth"].reshape(h, w, 1)
+    inst = prim["instanceIndex"].reshape(h, w, 1)
+    n_inst = len(casa.instances)
+    g_depth = np.where(depth <= 100000.0, depth * np.float32(1.25) + np.float32(0.5), depth).astype(np.float32)
+    g_inst = ((inst.astype(np.int64) + 3) % n_inst).astype(np.float32)
+    g_inst[::7, ::5] = 1000000.0          # names no instance
+    g_inst[3::11, 2::9] = -4.0
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    td, ti = device.Texture(gpu_ctx, g_depth), device.Texture(gpu_ctx, g_inst)
+    p.bind_texture("depthGBufferTexture", td)
+    p.bind_texture("instanceIndexGBufferTexture", ti)
+    osc.set_gbuffer(g_depth, np.zeros((h, w, 3), np.float32), np.zeros((h, w, 2), np.float32), g_inst)
+    jit = scene.mt19937_jitters(2)
+    ref = None
+    for s in (1, 2):
+        prm = scene.make_params(w, h, scene.casa_camera(), small_sky, spp=s, jitter=jit[s - 1], max_depth=3)
+        prm.WINDOW_W, prm.WINDOW_H = w + 32, h + 10
+        p.set_params(prm)
+        p.draw()
+        ref, _ = osc.render(prm, ref)
+    got = p.download()
+    for k in ref:
+        a, b = np.ascontiguousarray(got[k]), np.ascontiguousarray(ref[k])
+        assert np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))), k
+    # the images really were in play: depth is the raster's, albedo differs from the traced-only frame
+    plain = oracle_mod.OracleScene(casa, small_sky)
+    prm1 = scene.make_params(w, h, scene.casa_camera(), small_sky, spp=1, jitter=jit[0], max_depth=3)
+    base, _ = plain.render(prm1)
+    p.set_params(prm1)
+    p.draw()
+    one = p.download()
+    assert not np.array_equal(one["depth"], base["depth"]) and not np.array_equal(one["albedo"], base["albedo"])
+    assert np.array_equal(one["instanceIndex"], base["instanceIndex"]) and np.array_equal(one["normal"].view(np.uint32), base["normal"].view(np.uint32))
+    p.destroy()
+    td.release(); ti.release()
+    sb.release()

@@ -395,6 +395,7 @@ GLSL_FRAME_CASES = {
     "nosky": ("casa", 96, 54, 2, 1, dict(skybox_sampling=False)),
     "nolight": ("casa", 64, 36, 2, 1, dict(skybox_lighting=False)),
     "synth": ("synth", 112, 63, 3, 1, {}),
+    "raster": ("casa", 96, 54, 2, 1, {}),   # raster images that disagree with the traced hit (stored in the fixture)
 }
 
 
@@ -412,8 +413,11 @@ def test_frames_of_the_reference_shader_run_as_cpp(casa, oracle_mod, tag):
              0.001 turns a last-bit difference of a sampled direction into tens of per cent, so only
              a share of the pixels can agree to 1e-3 (measured when the fixture was made:
              direct light >= 99.98 %, indirect light >= 99.3 %); asserted a little below that.
-    depth is left out: with RasterizaionFor1st off the shader still writes the LINEAR-filtered raster
-    depth (pathtracing.glsl:615, :684), the pass writes the traced distance (a stated deviation)."""
+    depth: with RasterizaionFor1st off the shader still writes the LINEAR-filtered raster depth
+    (pathtracing.glsl:615, :684).  The "raster" case gives shader and oracle raster images that disagree
+    with the traced hit (depth scaled, instance index rotated) and compares depth and albedo too; the
+    other cases ran the oracle without raster images (it then writes the traced distance), so their depth
+    is compared away from silhouettes only."""
     import os
     from conftest import GOLDEN
     from raytracing_amd import scene
@@ -427,11 +431,16 @@ def test_frames_of_the_reference_shader_run_as_cpp(casa, oracle_mod, tag):
     sky = scene.procedural_sky(256, 128)
     osc = oracle_mod.OracleScene(sd, sky)
     jit = scene.mt19937_jitters(spp)
+    with_raster = "%s_gbuf_depth" % tag in k.files
+    if with_raster:
+        # the shader was given these raster images; with RasterizaionFor1st off it takes the depth output and the
+        # instance index of the albedo lookup from them (pathtracing.glsl:615-616, :641, :684), and so must the oracle
+        osc.set_gbuffer(k["%s_gbuf_depth" % tag], np.zeros((h, w, 3), np.float32), np.zeros((h, w, 2), np.float32), k["%s_gbuf_inst" % tag])
     acc = None
     for s in range(1, spp + 1):
         prm = scene.make_params(w, h, camera, sky, spp=s, frame=1, jitter=jit[s - 1], max_depth=max_depth, light_count=len(sd.lights), **switches)
         acc, _ = osc.render(prm, acc)
-    for name in ("albedo", "motion", "normal", "instanceIndex", "directLum", "indirectLum"):
+    for name in ("albedo", "motion", "normal", "instanceIndex", "directLum", "indirectLum") + (("depth",) if with_raster else ()):
         a, b = acc[name].reshape(h, w, -1), k["%s_fixed_%s" % (tag, name)]
         same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), "%s %s: %d words differ from the reference shader's" % (tag, name, int((~same).sum()))
