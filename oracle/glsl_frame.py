@@ -140,8 +140,24 @@ CASES = {
     # with RasterizaionFor1st off the shader still writes the raster depth and looks the albedo up through the
     # raster instance index (pathtracing.glsl:615-616, :641, :684)
     "raster": ("casa", 96, 54, 2, 1, {}),
+    # RasterizaionFor1st ON (the reference's default): no primary ray, the first vertex is rebuilt from the raster
+    # images (:606-624) -- distance, an unnormalised normal, arbitrary uv, instance index, clear colour where empty
+    "rfirst": ("casa", 96, 54, 2, 1, dict(raster_first=True)),
 }
 PERTURBED = ("raster",)
+RASTER_FIRST = ("rfirst",)
+
+
+def raster_first_images(prim, h, w):
+    depth = prim["depth"].reshape(h, w, 1).copy()
+    normal = (prim["normal"].reshape(h, w, 3) * np.float32(2.5)).astype(np.float32)
+    inst = prim["instanceIndex"].reshape(h, w, 1).copy()
+    miss = inst[..., 0] < 0
+    inst[miss] = 1000000.0
+    normal[miss] = 1000000.0
+    uv = np.random.default_rng(4).random((h, w, 2), np.float32)
+    uv[miss] = 1000000.0
+    return depth, normal, uv, inst
 
 
 def perturb(depth, inst, n_inst):
@@ -181,6 +197,12 @@ def main():
             if tag in PERTURBED:
                 g_depth, g_inst = perturb(g_depth, g_inst, len(sd.instances))
                 out["%s_gbuf_depth" % tag], out["%s_gbuf_inst" % tag] = g_depth, g_inst
+            if tag in RASTER_FIRST:
+                g = raster_first_images(prim, h, w)
+                for name, img in zip(("depth", "normal", "uv", "inst"), g):
+                    out["%s_gbuf_%s" % (tag, name)] = img
+                gbufs.append(g)
+                continue
             gbufs.append((g_depth, prim["normal"].reshape(h, w, 3), np.zeros((h, w, 2), np.float32), g_inst))
         prm = scene.make_params(w, h, camera, sky, spp=1, frame=1, jitter=jit[0], max_depth=max_depth, light_count=len(sd.lights), **switches)
         for kind2, exe in exes.items():

@@ -396,6 +396,7 @@ GLSL_FRAME_CASES = {
     "nolight": ("casa", 64, 36, 2, 1, dict(skybox_lighting=False)),
     "synth": ("synth", 112, 63, 3, 1, {}),
     "raster": ("casa", 96, 54, 2, 1, {}),   # raster images that disagree with the traced hit (stored in the fixture)
+    "rfirst": ("casa", 96, 54, 2, 1, dict(raster_first=True)),   # RasterizaionFor1st on: first vertex from the raster images
 }
 
 
@@ -435,7 +436,9 @@ def test_frames_of_the_reference_shader_run_as_cpp(casa, oracle_mod, tag):
     if with_raster:
         # the shader was given these raster images; with RasterizaionFor1st off it takes the depth output and the
         # instance index of the albedo lookup from them (pathtracing.glsl:615-616, :641, :684), and so must the oracle
-        osc.set_gbuffer(k["%s_gbuf_depth" % tag], np.zeros((h, w, 3), np.float32), np.zeros((h, w, 2), np.float32), k["%s_gbuf_inst" % tag])
+        g_normal = k["%s_gbuf_normal" % tag] if "%s_gbuf_normal" % tag in k.files else np.zeros((h, w, 3), np.float32)
+        g_uv = k["%s_gbuf_uv" % tag] if "%s_gbuf_uv" % tag in k.files else np.zeros((h, w, 2), np.float32)
+        osc.set_gbuffer(k["%s_gbuf_depth" % tag], g_normal, g_uv, k["%s_gbuf_inst" % tag])
     acc = None
     for s in range(1, spp + 1):
         prm = scene.make_params(w, h, camera, sky, spp=s, frame=1, jitter=jit[s - 1], max_depth=max_depth, light_count=len(sd.lights), **switches)
