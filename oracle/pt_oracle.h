@@ -15,8 +15,11 @@
  *   - its GLSL compiled as C++ against the glm headers it vendors (oracle/glsl_kat.py,
  *     oracle/glsl_frame.py; fixtures tests/golden/glsl_bsdf_kat.npz, glsl_frame_casa.npz):
  *     both BSDFs and the Sobol sampler query by query, and the whole fragment shader one
- *     main() per pixel on six configurations.  With the shader's sin / cos / atan / asin / pow
- *     resolved to the recipe below, every output word of those frames equals this oracle's.
+ *     main() per pixel on eight configurations (raster images in play and RasterizaionFor1st
+ *     on among them).  With the shader's sin / cos / atan / asin / pow resolved to the recipe
+ *     below, every output word of those frames equals this oracle's.  The post-processing
+ *     restatements (orc_post_*, orc_svgf_*, orc_taa) are pinned the same way against
+ *     shader/postprocessing/*.glsl (oracle/glsl_post.py, tests/golden/glsl_post.npz).
  * Still unpinned: what GLSL itself leaves open (a driver's transcendentals and texture
  * filtering), and the inputs of the raster pass.
  *

@@ -7,6 +7,7 @@ import struct
 import zlib
 
 import numpy as np
+import pytest
 
 
 def test_merge_matches_transcription(oracle_mod):
@@ -182,3 +183,54 @@ def test_taa_holds_a_static_image_and_clips_outliers(oracle_mod):
     cur = (rng.random((n, 3))).astype(np.float32)
     out = oracle_mod.taa(w, h, cur, flat, zero2, normal, inst, -normal, inst).reshape(n, 3)
     assert np.array_equal(out, cur)
+
+
+GLSL_POST_TAGS = ["SVGF_Merge", "StaticBlender@1", "StaticBlender@2", "StaticBlender@9", "ToneMappingGamma", "SVGF_TemporalFilter@0",
+                  "SVGF_TemporalFilter@1", "SVGF_VarianceFilter", "SVGF_SpatialFilter@1", "SVGF_SpatialFilter@4", "TAA"]
+
+
+@pytest.mark.parametrize("tag", GLSL_POST_TAGS)
+def test_post_shaders_of_the_reference_run_as_cpp(oracle_mod, tag):
+    """tests/golden/glsl_post.npz: the reference's post-processing fragment shaders
+    (shader/postprocessing/SVGF_Merge, StaticBlender, ToneMappingGamma, SVGF_TemporalFilter, SVGF_VarianceFilter,
+    SVGF_SpatialFilter, TAA .glsl) executed as C++, one main() per pixel, against the glm headers the reference vendors
+    (oracle/glsl_post.py lists the mechanical rewrites of GLSL-only declarations it makes), on a 40x24 frame with two
+    surfaces, fireflies, NaN / Inf texels, motion inside and outside the frame, agreeing and disagreeing history.
+      fixed  the shaders' exp / pow resolve to the recipes the oracle and the HIP path share: the oracle's restatement
+             must reproduce every output WORD;
+      libm   the C library's exp / pow ("some other GL driver"): within 1e-5 relative."""
+    import os
+    from conftest import GOLDEN
+    k = np.load(os.path.join(GOLDEN, "glsl_post.npz"))
+    w, h = [int(x) for x in k["size"]]
+    name = tag.split("@")[0]
+    arg = int(tag.split("@")[1]) if "@" in tag else None
+    n_in = {"SVGF_Merge": 4, "StaticBlender": 3, "ToneMappingGamma": 2, "SVGF_TemporalFilter": 12, "SVGF_VarianceFilter": 5,
+            "SVGF_SpatialFilter": 5, "TAA": 8}[name]
+    a = [k["%s_in%d" % (tag, i)] for i in range(n_in)]
+    if name == "SVGF_Merge":
+        got = {0: oracle_mod.post_merge(a[1], a[2], a[3])}
+    elif name == "StaticBlender":
+        hc, hm = oracle_mod.post_static_blend(arg, a[0], a[1], a[2])
+        got = {1: hc, 2: hm}
+    elif name == "ToneMappingGamma":
+        got = {1: oracle_mod.post_tonemap(a[0])}
+    elif name == "SVGF_TemporalFilter":
+        oc, om, on = oracle_mod.svgf_temporal(w, h, arg, a[0], a[1], a[2], a[3], a[7], a[8], a[9], a[10], a[11])
+        got = {4: oc, 5: om, 6: on}
+    elif name == "SVGF_VarianceFilter":
+        got = {4: oracle_mod.svgf_variance(w, h, a[0], a[1], a[2], a[3])}
+    elif name == "SVGF_SpatialFilter":
+        got = {4: oracle_mod.svgf_spatial(w, h, arg, a[0], a[1], a[2], a[3])}
+    else:
+        got = {7: oracle_mod.taa(w, h, a[0], a[1], a[2], a[3], a[4], a[5], a[6])}
+    for idx, g in got.items():
+        g = np.ascontiguousarray(g, np.float32).ravel()
+        ref = k["%s_fixed_out%d" % (tag, idx)]
+        same = (g.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(g) & np.isnan(ref))
+        assert same.all(), "%s buffer %d: %d words differ from the reference shader's" % (tag, idx, int((~same).sum()))
+        lib = k["%s_libm_out%d" % (tag, idx)]
+        rel = np.abs(g.astype(np.float64) - lib) / np.maximum(np.abs(lib.astype(np.float64)), 1e-6)
+        rel[np.isnan(g) & np.isnan(lib)] = 0.0
+        assert np.nanmax(rel) < 1e-5 and not np.isnan(rel).any(), (tag, idx, float(np.nanmax(rel)))
+        assert np.isfinite(ref).mean() > 0.9 and (np.unique(ref).size > 20 or ref.size == w * h)   # (a real frame; sample counts may be uniform)
