@@ -272,6 +272,22 @@ def test_sky_cache_follows_the_cdf(small_sky):
     assert abs(pdf.sum() / light_sum - 1.0) < 1e-9
 
 
+def test_sky_cache_bit_exact_with_the_reference_statements():
+    """tests/golden/sky_cache.npz: cache and light sum computed by the reference's own statements -- the CPU half of
+    Skybox::load_to_gpu (src/texture/Skybox.cpp, everything before its first OpenGL call), placed unchanged in a
+    function by oracle/sky_cache_ref.py -- for a 64x32 map with black rows, black runs, a sun and twelve orders of
+    magnitude (every texel compared), and for the procedural skies the tests (256x128, every texel) and the bench
+    (2048x1024, sha256) use."""
+    from raytracing_amd import scene
+    k = np.load(os.path.join(GOLDEN, "sky_cache.npz"))
+    s = scene.Sky(k["small_rgb"])
+    assert np.array_equal(s.cache.view(np.uint32), k["small_cache"].view(np.uint32)) and s.light_sum == k["small_light_sum"][0]
+    sky = scene.procedural_sky(256, 128)
+    assert np.array_equal(sky.cache.view(np.uint32), k["sky256_cache"].view(np.uint32)) and sky.light_sum == k["sky256_light_sum"][0]
+    big = scene.procedural_sky(2048, 1024)
+    assert hashlib.sha256(big.cache.tobytes()).digest() == k["sky2048_cache_sha256"].tobytes() and big.light_sum == k["sky2048_light_sum"][0]
+
+
 def test_mt19937_jitter_sequence():
     from raytracing_amd import scene
     j = scene.mt19937_jitters(3)
