@@ -312,6 +312,23 @@ def ref_scene_level(scene_data):
     return nodes, w2l, siz, depth
 
 
+def ref_transforms(records):
+    """records: (n, 20) float32 rows {fov_x, far, parent position/rotation_deg/scale, camera position/rotation_deg/
+    scale}.  Runs the reference's Transform::matrix (src/Transform.cpp:20-53), Instance::matrix_to_global
+    (src/instance/Instance.cpp:38-41) and Camera::w2v_matrix / v2w_matrix / projection (src/instance/Camera.cpp:13-43)
+    and returns ((screen_w, screen_h), (n, 6, 16) float32): parent matrix, camera matrix, camera to global, w2v, v2w,
+    projection, each as glm stores it (column major)."""
+    records = np.ascontiguousarray(records, np.float32).reshape(-1, 20)
+    with tempfile.TemporaryDirectory() as d:
+        with open(d + "/i.bin", "wb") as f:
+            f.write(struct.pack("<i", len(records)))
+            f.write(records.tobytes())
+        subprocess.check_call([REF_HARNESS, "transform", d + "/i.bin", d + "/o.bin"])
+        raw = open(d + "/o.bin", "rb").read()
+    wh = struct.unpack_from("<2i", raw, 0)
+    return wh, np.frombuffer(raw, np.float32, len(records) * 96, 8).reshape(-1, 6, 16).copy()
+
+
 def ref_mat_inverse(mats):
     mats = np.ascontiguousarray(mats, np.float32).reshape(-1, 16)
     with tempfile.TemporaryDirectory() as d:

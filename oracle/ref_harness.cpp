@@ -5,6 +5,7 @@
 // Driver around the reference's OWN compiled sources.  The Makefile next to this
 // file compiles, from where they lie under /root/reference (nothing is copied):
 //   src/BVH.cpp  src/AABB.cpp  src/Intersection.cpp
+//   src/Transform.cpp  src/instance/Instance.cpp  src/instance/Camera.cpp  (through ref_transform_unit.cpp)
 //   include/hdrloader.cpp  include/stb_image.cpp
 // and links them with this driver into oracle/_ref/ref_harness.  Everything
 // numerical (SAH build, std::sort tie order, slab / Moller-Trumbore tests, RGBE
@@ -290,8 +291,43 @@ static int cmd_stb(const char *in, const char *out) {
     return 0;
 }
 
+// Defined in ref_transform_unit.cpp, which compiles src/Transform.cpp, src/instance/Instance.cpp
+// and src/instance/Camera.cpp.
+void ref_transform_matrix(const float *prs9, float *out16);
+void ref_camera_matrices(float fov_x, float far_plane, const float *parent9, const float *cam9, float *out64,
+                         int *screen_wh_out);
+
+// transforms file : i32 n ; per item { f32 fov_x, far ; f32 parent[9] ; f32 cam[9] }   (9 = position, rotation in
+//                   degrees, scale)
+// out             : i32 screen_w, screen_h ; per item { f32 parent_matrix[16] ; f32 cam_matrix[16] ;
+//                   f32 cam_to_global[16] ; f32 w2v[16] ; f32 v2w[16] ; f32 projection[16] }
+static int cmd_transform(const char *in, const char *out) {
+    FILE *f = fopen(in, "rb");
+    if(!f) return 2;
+    int n = 0;
+    if(fread(&n, 4, 1, f) != 1) return 2;
+    std::vector<float> rec((size_t)n * 20);
+    if(fread(rec.data(), 4, rec.size(), f) != rec.size()) return 2;
+    fclose(f);
+    std::vector<float> res((size_t)n * 96);
+    int wh[2] = {0, 0};
+    for(int i = 0; i < n; i++) {
+        const float *r = &rec[(size_t)i * 20];
+        float *o = &res[(size_t)i * 96];
+        ref_transform_matrix(r + 2, o);
+        ref_transform_matrix(r + 11, o + 16);
+        ref_camera_matrices(r[0], r[1], r + 2, r + 11, o + 32, wh);
+    }
+    f = fopen(out, "wb");
+    fwrite(wh, 4, 2, f);
+    fwrite(res.data(), 4, res.size(), f);
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     std::string c = argc > 1 ? argv[1] : "";
+    if(c == "transform" && argc == 4) return cmd_transform(argv[2], argv[3]);
     if(c == "bvh" && argc == 4) return cmd_bvh(argv[2], argv[3]);
     if(c == "isect" && argc == 6) return cmd_isect(argv[2], argv[3], argv[4], argv[5]);
     if(c == "scene" && argc == 5) return cmd_scene(argv[2], argv[3], argv[4]);

@@ -39,7 +39,8 @@ Mat4 camera_projection(float fov_x, float far_plane, int screen_w, int screen_h)
                             0, 0, (n + f) / (f - n), -2 * n * f / (f - n),
                             0, 0, 1, 0};
     Mat4 m = Mat4::by_rows(rows);
-    for(int j = 0; j < 4; j++) m.c[j] = Vec4(-m.c[j].x, -m.c[j].y, -m.c[j].z, -m.c[j].w);
+    // glm's unary minus on a matrix is 0 - x per component (the vendored glm's type_vec4.inl), so zeros stay +0
+    for(int j = 0; j < 4; j++) m.c[j] = Vec4(0.0f - m.c[j].x, 0.0f - m.c[j].y, 0.0f - m.c[j].z, 0.0f - m.c[j].w);
     return m;
 }
 
