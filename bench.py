@@ -57,6 +57,9 @@ def parse():
                          "sliced over the ranks (the multi-GPU benchmark configuration: a fixed 256-spp frame cut over 2/4/8 GPUs)")
     ap.add_argument("--collective", default="capi", choices=["capi", "torch"],
                     help="N > 1: combine through the library's own pt_pass_allreduce (RCCL, default) or through torch.distributed")
+    ap.add_argument("--traversal", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="pt_pass_set_traversal: 0 the library's choice, 1 reference order, 2 ordered over the two levels, "
+                         "3 ordered over the flattened tree whatever the scene's size")
     ap.add_argument("--tail", type=int, default=-1,
                     help="pt_pass_set_tail_threshold for the timed region: -1 the library's choice, 0 no tail launch (the counter "
                          "passes of tools/run_pmc.sh use --pipeline 1 --tail 0: the launches the roofline leg times)")
@@ -149,6 +152,7 @@ def main():
     p = device.PathTracingPass(ctx, W if wl != "casa_isect" else 16, H if wl != "casa_isect" else 16)
     p.bind_scene(sb)
     p.set_wide_nodes(args.wide_nodes)
+    p.set_traversal(args.traversal)
     p.set_material_grouping(args.material_grouping)
     p.set_tail_threshold(args.tail)
     if wl != "casa_isect":
@@ -333,6 +337,7 @@ def main():
                        "resolution": [W, H] if wl != "casa_isect" else None,
                        "triangles": int(len(sd.triangles)), "instances": int(len(sd.instances)),
                        "draws_in_flight": args.pipeline if wl != "casa_isect" else None,
+                       "traversal": args.traversal, "flat_leaves": p.stats()["flat_leaves"],
                        "parallelism": "sample slicing x%d, one all-reduce" % world if world > 1 else "single GPU",
                        "collective": collective if wl != "casa_isect" else None,
                        "total_spp": total_spp if wl != "casa_isect" else None,

@@ -192,7 +192,9 @@ typedef struct pt_stats {
      * equivalence to the reference's order rests on that nesting, so such buffers are traced
      * in the reference's order whatever pt_pass_set_traversal says.  Not reset. */
     uint64_t reference_order_forced;
-    uint64_t reserved[1];
+    /* (instance, triangle) pairs in the flattened tree the ordered traversal currently walks (see
+     * pt_pass_set_traversal), 0 while it walks the two levels.  Not reset. */
+    uint64_t flat_leaves;
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 
@@ -201,8 +203,21 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
  *     batched leaves); rays whose closest hit the reference's order-dependent pruning could
  *     have dropped (a second hit at the same distance, or nearer than the boxes that lead
  *     to the closest one) are traced again in the reference's order, so results are those
- *     of mode 1;
- *   1 the reference's visiting order for every ray (shader/pathtracing.glsl:254-316). */
+ *     of mode 1.  Once the scene buffers (slots 2-5) have stood still for one draw, or at
+ *     pt_pass_prepare, a scene of up to 4 Mi (instance, triangle) pairs is also laid out as ONE
+ *     tree in world space -- unless an instance is rotated off the coordinate axes (then the
+ *     boxes of that tree would be loose and the two levels are faster) -- which the ordered
+ *     traversal then walks instead of the scene level
+ *     and the mesh level in turn (a ray is moved into an instance's space only where a triangle
+ *     is tested, with the reference's arithmetic; the boxes are widened by what that move can
+ *     round away, so the candidates, hence the results, stay those of mode 1).  Host work of
+ *     about 10 ms per 100 k pairs and 150 bytes of device memory per pair; a scene whose
+ *     instances move every frame never pays it.  Scenes with singular or badly conditioned
+ *     instance matrices keep the two levels.  pt_stats.flat_leaves tells which tree is walked;
+ *   1 the reference's visiting order for every ray (shader/pathtracing.glsl:254-316);
+ *   2 as 0, but never the flattened tree;
+ *   3 as 0, with the flattened tree built at the next draw / intersect / prepare whatever the
+ *     scene's size (up to 128 Mi pairs) and however its instances are rotated. */
 int pt_pass_set_traversal(pt_pass *pass, int mode);
 
 /* Node format of the ordered traversal; no counterpart in the reference, results do not depend
@@ -403,6 +418,18 @@ int pt_host_build_scene(const float *mesh_root_box, const int32_t *mesh_siz, con
 int pt_host_check_traversal_layout(const void *mesh_nodes, size_t n_mesh_nodes, const void *tris, size_t n_tris,
                                    const void *scene_nodes, size_t n_scene_nodes, const void *instances, size_t n_inst,
                                    int32_t format, uint64_t counts_out[4]);
+/* No counterpart in the reference (test and debugging aid; no GPU).  Builds the flattened tree of
+ * pt_pass_set_traversal from reference-format buffers and checks it independently: it reaches every
+ * (instance, triangle) pair exactly once, every leaf carries its instance's matrix, its triangle
+ * and the box of the triangle's parent in the reference's mesh BVH, every child box as the kernel
+ * decodes it contains the world-space image of those parent boxes, the stack bound holds.
+ * counts_out: leaves, wide nodes, child boxes checked, planes that decode to "unbounded"; all 0
+ * when this scene gets no flattened tree, with the reason in why_not (optional, why_cap bytes).
+ * only_axis_aligned: refuse scenes with instances rotated off the axes, as the default traversal
+ * mode does.  PT_ERR_INVALID when the buffers are refused, PT_ERR_STATE when a check fails. */
+int pt_host_check_flat_layout(const void *mesh_nodes, size_t n_mesh_nodes, const void *tris, size_t n_tris,
+                              const void *scene_nodes, size_t n_scene_nodes, const void *instances, size_t n_inst,
+                              int32_t only_axis_aligned, uint64_t counts_out[4], char *why_not, size_t why_cap);
 /* Transform::matrix, src/Transform.cpp:20-53 */
 int pt_host_transform_matrix(const float position[3], const float rotation_deg[3], const float scale[3],
                              float out16[16]);

@@ -48,7 +48,7 @@ class PtStats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64), ("rays_extend", C.c_uint64), ("rays_shadow", C.c_uint64),
         ("draws", C.c_uint64), ("rays_retraced", C.c_uint64), ("mesh_level_builds", C.c_uint64),
-                ("scene_level_builds", C.c_uint64), ("debug", C.c_uint64 * 3), ("reference_order_forced", C.c_uint64), ("reserved", C.c_uint64 * 1),
+                ("scene_level_builds", C.c_uint64), ("debug", C.c_uint64 * 3), ("reference_order_forced", C.c_uint64), ("flat_leaves", C.c_uint64),
     ]
 
 
@@ -139,6 +139,8 @@ SIGNATURES = {
                                                  C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "pt_host_build_scene": (C.c_int, [f32p, i32p, i32p, C.c_int32, f32p, i32p, i32p, C.c_int32,
                                       C.c_void_p, C.c_void_p, i32p]),
+    "pt_host_check_flat_layout": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_int32, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
     "pt_host_transform_matrix": (C.c_int, [f32p, f32p, f32p, f32p]),
     "pt_host_mat4_mul": (C.c_int, [f32p, f32p, f32p]),
     "pt_host_mat4_inverse": (C.c_int, [f32p, f32p]),

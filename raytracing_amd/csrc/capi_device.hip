@@ -96,7 +96,15 @@ struct pt_pass {
     uint64_t mesh_level_builds = 0, scene_level_builds = 0;
     DeviceArray d_mesh_buf, d_scene_buf, d_spill, d_tex_table;  // the two traversal buffers (device_types.h)
     DeviceArray d_redo_isect;  // redo list of the ordered intersect
-    int traversal_mode = 0;               // 0 ordered + exact fallback, 1 reference order only
+    int traversal_mode = 0;               // pt_pass_set_traversal
+    // The flattened tree (trace_flat.h): built once the scene has stood still for a draw (or at once: mode 3,
+    // pt_pass_prepare), dropped when slots 2-5 change.  flat_refused: this scene gets none (flat_reason says why).
+    bool flat_valid = false, flat_refused = false, flat_forced = false;  // flat_forced: built under mode 3
+    int flat_unchanged = 0;
+    AccelFlat flat;  // (slots cleared after upload)
+    DeviceArray d_flat_buf;
+    std::string flat_reason;
+    uint64_t flat_builds = 0;
     int quantise = -1;                    // wide nodes: 0 WNodes, 1 or -1 (default) QNodes
     int n_textures = 0;
     int spill_depth = 0;
@@ -230,7 +238,7 @@ void slot_mark(pt_pass *p, int s) {
 
 // (Re)builds whatever the bound scene buffers changed: traversal layout from slots 2-5,
 // texture descriptor table from slot 0, and validates material pointers against slot 1.
-int prepare_scene(pt_pass *p) {
+int prepare_scene(pt_pass *p, bool eager = false) {
     pt_ctx *ctx = p->ctx;
     for(int s = PT_SLOT_MATERIAL; s <= PT_SLOT_SCENE_BVH; s++)
         if(!p->slots[s] || p->slots[s]->bytes == 0)
@@ -242,6 +250,12 @@ int prepare_scene(pt_pass *p) {
     const bool mat_changed = slot_changed(p, PT_SLOT_MATERIAL);
     const bool scene_changed = mesh_changed || !p->scene_level_valid || slot_changed(p, PT_SLOT_INSTANCE_INFO) ||
                                slot_changed(p, PT_SLOT_SCENE_BVH) || mat_changed;
+    if(mesh_changed || !p->scene_level_valid || slot_changed(p, PT_SLOT_INSTANCE_INFO) || slot_changed(p, PT_SLOT_SCENE_BVH)) {
+        // (a new material buffer alone leaves the geometry, hence the flattened tree, as it is)
+        p->flat_valid = false;
+        p->flat_refused = false;
+        p->flat_unchanged = 0;
+    }
     if(scene_changed || mat_changed) {
         std::vector<uint8_t> t_inst, t_mats, t_tris, t_mesh, t_scene;
         const uint8_t *inst = nullptr, *mats = nullptr, *tris = nullptr, *mesh = nullptr, *scene = nullptr;
@@ -361,6 +375,58 @@ int prepare_scene(pt_pass *p) {
         slot_mark(p, PT_SLOT_INSTANCE_INFO);
         slot_mark(p, PT_SLOT_MATERIAL);
     }
+    // ---- the flattened tree
+    const bool flat_wanted = (p->traversal_mode == 0 || p->traversal_mode == 3) && p->quantise != 0 && p->mesh_level.nested && p->scene_level.nested;
+    if(flat_wanted && !p->flat_valid && !p->flat_refused) {
+        if(!eager && p->traversal_mode != 3 && p->flat_unchanged < 1) {
+            p->flat_unchanged++;  // (instances that move every frame never get here twice in a row)
+        } else {
+            std::vector<uint8_t> t_inst, t_tris, t_mesh, t_scene;
+            const uint8_t *inst = nullptr, *tris = nullptr, *mesh = nullptr, *scene = nullptr;
+            pt_buf *b_inst = p->slots[PT_SLOT_INSTANCE_INFO], *b_tris = p->slots[PT_SLOT_TRIANGLE], *b_mesh = p->slots[PT_SLOT_MESH_BVH],
+                   *b_scene = p->slots[PT_SLOT_SCENE_BVH];
+            int rc;
+            size_t cap = p->traversal_mode == 3 ? (size_t)1 << 27 : (size_t)1 << 22;
+            if(const char *e = getenv("RTA_FLAT_MAX_LEAVES")) cap = (size_t)strtoull(e, nullptr, 10);
+            // (the triangle count bounds the leaves from below: do not read the big arrays back for nothing)
+            if(b_tris->bytes / sizeof(TriangleRec) > cap) {
+                p->flat_refused = true;
+                p->flat_reason = "more triangles than the flattened tree is built for";
+            } else {
+                if((rc = host_view(b_inst, t_inst, &inst))) return rc;
+                if((rc = host_view(b_tris, t_tris, &tris))) return rc;
+                if((rc = host_view(b_mesh, t_mesh, &mesh))) return rc;
+                if((rc = host_view(b_scene, t_scene, &scene))) return rc;
+                AccelFlat &fl = p->flat;
+                std::string why;
+                if(build_accel_flat(reinterpret_cast<const BVHNodeInfo *>(mesh), b_mesh->bytes / sizeof(BVHNodeInfo),
+                                    reinterpret_cast<const TriangleRec *>(tris), b_tris->bytes / sizeof(TriangleRec),
+                                    reinterpret_cast<const BVHNodeInfo *>(scene), b_scene->bytes / sizeof(BVHNodeInfo),
+                                    reinterpret_cast<const InstanceInfo *>(inst), b_inst->bytes / sizeof(InstanceInfo), cap, p->traversal_mode != 3, 0, fl, why)) {
+                    if((rc = upload_array(ctx, p->d_flat_buf, fl.slots.data(), fl.slots.size() * sizeof(TNode)))) return rc;
+                    std::vector<TNode>().swap(fl.slots);
+                    const int need = fl.max_stack + 2 - FAST_LDS_STACK;
+                    const char *cap_env = getenv("RTA_SPILL_DEPTH_CAP");
+                    if(need > p->spill_depth && !(cap_env && *cap_env)) {
+                        JOIN_TRY(ctx);
+                        HIP_TRY(hipStreamSynchronize(ctx->stream));
+                        p->spill_depth = need;
+                        const size_t nthreads = (size_t)p->trace_blocks * TRACE_BLOCK;
+                        if((rc = p->d_spill.ensure(nthreads * (size_t)p->spill_depth * sizeof(uint2)))) return rc;
+                    }
+                    p->flat_valid = true;
+                    p->flat_forced = p->traversal_mode == 3;
+                    p->flat_builds++;
+                    p->flat_reason.clear();
+                } else {
+                    p->flat_refused = true;
+                    p->flat_reason = why;
+                }
+                release_large_shadow(b_tris);
+                release_large_shadow(b_mesh);
+            }
+        }
+    }
     if(slot_changed(p, PT_SLOT_TEXTURE_HANDLES) || !p->d_tex_table.p) {
         std::vector<TexDesc> table;
         pt_buf *hb = p->slots[PT_SLOT_TEXTURE_HANDLES];
@@ -409,7 +475,7 @@ void set_draw_grid(pt_pass *p) {
 
 // The ordered traversal is equivalent to the reference's order only when child boxes lie
 // inside their parents' boxes; other buffers are traced in the reference's order.
-bool use_ordered(const pt_pass *p) { return p->traversal_mode == 0 && p->mesh_level.nested && p->scene_level.nested; }
+bool use_ordered(const pt_pass *p) { return p->traversal_mode != 1 && p->mesh_level.nested && p->scene_level.nested; }
 
 // spill == nullptr: the pass's own spill area (launches on the main stream)
 TraceScene make_trace_scene(pt_pass *p, void *spill = nullptr) {
@@ -480,6 +546,11 @@ FastScene make_fast_scene(pt_pass *p, void *spill = nullptr) {
     sc.mesh_buf = static_cast<const char *>(p->d_mesh_buf.p);
     sc.scene_buf = static_cast<const char *>(p->d_scene_buf.p);
     sc.hdr = p->scene_level.header;
+    const bool flat = p->flat_valid && (p->traversal_mode == 0 || p->traversal_mode == 3);
+    sc.flat_buf = flat ? static_cast<const char *>(p->d_flat_buf.p) : nullptr;
+    sc.flat_root_ref = p->flat.root_ref;
+    sc.flat_pad = p->flat.pad;
+    sc.flat_reach = p->flat.reach;
     sc.spill = static_cast<uint2 *>(spill ? spill : p->d_spill.p);
     sc.spill_depth = p->spill_depth;
     sc.error_flag = p->d_err_flag;
@@ -899,7 +970,7 @@ int pt_pass_destroy(pt_pass *p) {
     collect_profile(p);
     for(hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
     for(pt_pass::Lane &l : p->lanes) release_lane(l);
-    DeviceArray *arrs[] = {&p->d_mesh_buf, &p->d_scene_buf, &p->d_redo_isect,
+    DeviceArray *arrs[] = {&p->d_mesh_buf, &p->d_scene_buf, &p->d_flat_buf, &p->d_redo_isect,
                            &p->d_spill, &p->d_tex_table, &p->d_counters, &p->d_stats, &p->d_err};
     for(DeviceArray *a : arrs) a->release();
     if(p->h_err) (void)hipHostFree(p->h_err);
@@ -1199,6 +1270,7 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     out->draws = raw[3];
     out->rays_retraced = raw[4];
     out->mesh_level_builds = pass->mesh_level_builds;
+    out->flat_leaves = pass->flat_valid ? (uint64_t)pass->flat.n_leaves : 0;
     out->reference_order_forced = pass->mesh_level_valid && pass->scene_level_valid && !(pass->mesh_level.nested && pass->scene_level.nested) ? 1 : 0;
     out->scene_level_builds = pass->scene_level_builds;
     HIP_TRY(hipMemcpy(out->debug, static_cast<char *>(pass->d_err.p) + 16, 24, hipMemcpyDeviceToHost));
@@ -1211,7 +1283,12 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
 
 int pt_pass_set_traversal(pt_pass *pass, int mode) {
     if(!pass) return fail(PT_ERR_INVALID, "pt_pass_set_traversal: null pass");
-    if(mode != 0 && mode != 1) return fail(PT_ERR_INVALID, "pt_pass_set_traversal: mode must be 0 (ordered) or 1 (reference order)");
+    if(mode < 0 || mode > 3)
+        return fail(PT_ERR_INVALID, "pt_pass_set_traversal: mode must be 0 (ordered), 1 (reference order), 2 (ordered, two levels only) or 3 (ordered, flattened tree at once)");
+    if(mode != pass->traversal_mode) {
+        pass->flat_refused = false;  // (mode 3 builds what mode 0 refuses)
+        if(pass->flat_valid && mode == 0 && pass->flat_forced) pass->flat_valid = false;  // mode 0 decides for itself
+    }
     pass->traversal_mode = mode;
     return PT_OK;
 }
@@ -1219,7 +1296,7 @@ int pt_pass_set_traversal(pt_pass *pass, int mode) {
 int pt_pass_prepare(pt_pass *pass) {
     if(!pass) return fail(PT_ERR_INVALID, "pt_pass_prepare: null pass");
     HIP_TRY(hipSetDevice(pass->ctx->device));
-    int rc = prepare_scene(pass);
+    int rc = prepare_scene(pass, true);
     if(rc) return rc;
     // the path state of every draw that may be in flight (a draw allocates its lane's at first use otherwise:
     // eleven device allocations, a millisecond or two inside somebody's frame)

@@ -110,6 +110,37 @@ int pt_host_check_traversal_layout(const void *mesh_nodes, size_t n_mesh_nodes, 
     return PT_OK;
 }
 
+int pt_host_check_flat_layout(const void *mesh_nodes, size_t n_mesh_nodes, const void *tris, size_t n_tris, const void *scene_nodes,
+                              size_t n_scene_nodes, const void *instances, size_t n_inst, int32_t only_axis_aligned,
+                              uint64_t counts_out[4], char *why_not, size_t why_cap) {
+    if(!mesh_nodes || !tris || !scene_nodes || !instances) return fail(PT_ERR_INVALID, "pt_host_check_flat_layout: null argument");
+    const BVHNodeInfo *mesh = static_cast<const BVHNodeInfo *>(mesh_nodes), *scene = static_cast<const BVHNodeInfo *>(scene_nodes);
+    const InstanceInfo *inst = static_cast<const InstanceInfo *>(instances);
+    const TriangleRec *tr = static_cast<const TriangleRec *>(tris);
+    std::string err;
+    {
+        // (the flat builder relies on what these two have validated)
+        AccelMeshLevel ml;
+        AccelSceneLevel sl;
+        if(!build_accel_mesh_level(mesh, n_mesh_nodes, tr, n_tris, {}, 1, ml, err)) return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
+        bool missing = false;
+        bool ok = build_accel_scene_level(mesh, n_mesh_nodes, ml, scene, n_scene_nodes, inst, n_inst, sl, err, &missing);
+        if(!ok && !missing) return fail(PT_ERR_INVALID, "scene buffers rejected: " + err);
+    }
+    if(why_not && why_cap) why_not[0] = 0;
+    uint64_t counts[4] = {0, 0, 0, 0};
+    AccelFlat fl;
+    std::string why;
+    if(!build_accel_flat(mesh, n_mesh_nodes, tr, n_tris, scene, n_scene_nodes, inst, n_inst, (size_t)1 << 27, only_axis_aligned != 0, 0, fl, why)) {
+        if(why_not && why_cap) snprintf(why_not, why_cap, "%s", why.c_str());
+        if(counts_out) memcpy(counts_out, counts, sizeof counts);
+        return PT_OK;
+    }
+    if(!verify_accel_flat(mesh, n_mesh_nodes, tr, inst, n_inst, fl, counts, err)) return fail(PT_ERR_STATE, "flat layout check failed: " + err);
+    if(counts_out) memcpy(counts_out, counts, sizeof counts);
+    return PT_OK;
+}
+
 int pt_host_transform_matrix(const float position[3], const float rotation_deg[3], const float scale[3],
                              float out16[16]) {
     if(!position || !rotation_deg || !scale || !out16) return fail(PT_ERR_INVALID, "pt_host_transform_matrix: null argument");

@@ -87,6 +87,22 @@ struct alignas(64) TLeaf {
 };
 static_assert(sizeof(TLeaf) == 64, "triangle leaf record is 64 bytes");
 
+// One triangle of one instance in the flattened tree (trace_flat.h), 128 bytes, at an even slot: the TLeaf of
+// the triangle (box of its reference parent and the triangle, both in the instance's space), then the rows of
+// the instance's world-to-local matrix as in InstAccel, then the instance index -- everything a ray needs to
+// run the reference's test on this triangle arrives with one fetch.
+struct alignas(64) FlatLeaf {
+    float parent_lo[3], parent_hi[3];
+    float v0[3];
+    float e1[3];
+    float e2[3];
+    uint32_t triangle;
+    float row[3][4];
+    uint32_t instance;
+    uint32_t pad[3];
+};
+static_assert(sizeof(FlatLeaf) == 128, "flattened leaf record is 128 bytes");
+
 // Per-instance record, 128 bytes.  row[r] = (m[0][r], m[1][r], m[2][r], m[3][r]) of the
 // column-major world-to-local matrix, i.e. local = row . (world, 1).  The first 64 bytes are
 // all a ray needs to enter the instance.

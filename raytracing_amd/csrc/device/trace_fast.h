@@ -58,6 +58,11 @@ struct FastScene {
     const char *mesh_buf;    // TNodes and TLeafs of all meshes (64-byte slots)
     const char *scene_buf;   // scene TNodes, then InstAccels (two slots each)
     SceneHeader hdr;
+    // the flattened tree (trace_flat.h), or null: FlatLeafs (two slots each), then its QNodes
+    const char *flat_buf;
+    uint32_t flat_root_ref;
+    float flat_pad;    // box padding per unit of |origin| + flat_reach, see trace_flat.h
+    float flat_reach;  // sum over the axes of the largest |coordinate| of the scene box
     uint2 *spill;
     int spill_depth;
     unsigned *error_flag;

@@ -1,0 +1,252 @@
+// Ordered closest-hit / occlusion traversal over ONE tree for the whole scene.
+//
+// trace_fast.h walks the reference's two levels: scene nodes in world space, an instance entry
+// that moves the ray into the instance's space, then the mesh's nodes.  Of the 21 steps a
+// path ray of the reference's demo scene takes there, 5.5 are scene nodes and instance
+// entries.  Here every (instance, triangle) pair is a leaf of one four-wide tree built in
+// WORLD space (host: build_accel_flat); the ray stays in world space while it walks, and is
+// moved into an instance's space only where a triangle is tested -- with the same arithmetic,
+// so the test itself is the reference's, bit for bit.
+//
+// Why this still returns the reference's answer: trace_fast.h's argument needs (1) culling that
+// never drops a CANDIDATE (a triangle whose reference parent box passes in the instance's space
+// and whose instance's scene leaf box passes in world space), (2) a hit accepted only for a
+// candidate, (3) pruning beyond the near-tie band only, (4) the runner-up bookkeeping.  (2)-(4)
+// are kept as they are: a leaf record carries the exact parent box, the instance record the
+// exact scene leaf box, and both are tested with the reference's IEEE slab test before a closer
+// hit is accepted.  For (1) the tree's boxes must contain, in world space, every point at which
+// the reference could accept a hit on the leaf's triangle.  Such a point p_l = o_l + t d_l lies
+// in the parent box B (up to the rounding of the reference's own slab test), with
+// o_l = fl(W o), d_l = fl(W d) for the instance's world-to-local matrix W.  With A = W^-1:
+//     o + t d = A p_l - A (e_o + t e_d),   |e_o| + t |e_d| <= 4 u |W| (|o| + t |d|)
+// so the leaf's world box is the box of the eight corners of B under A (computed in double,
+// rounded outwards), and what remains is an ABSOLUTE error of at most 4 u cond (|o| + t|d|),
+// cond = || |A| |W| ||.  It is covered per ray: every box is widened by
+//     pad = flat_pad * (|o|_1 + flat_reach),   flat_pad = 64 u max cond over the instances,
+// flat_reach = the largest |coordinate| sum of the scene box (t |d| <= |o| + reach for any hit),
+// at no cost per node: near planes are met from the origin moved by pad along the ray's
+// direction signs, far planes from the origin moved the other way.  The host builds no flat
+// tree when an instance's matrix is singular or cond exceeds 256.
+#pragma once
+#include "trace_fast.h"
+
+namespace rta {
+
+template <class Feed = WaveRayFeed, class Source, class Sink>
+__device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sink &sink, unsigned *next_ray,
+                                           unsigned n_rays, uint2 *s_stack) {
+    constexpr int REFILL_BELOW = RT_FAST_REFILL;
+#ifndef RT_FLAT_LEAF_BATCH
+#define RT_FLAT_LEAF_BATCH 12
+#endif
+    constexpr int LEAF_BATCH = RT_FLAT_LEAF_BATCH, SERVE_ALL_BELOW = RT_SERVE_ALL_BELOW;
+    const unsigned tid = threadIdx.x;
+    const unsigned gtid = blockIdx.x * blockDim.x + tid;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+
+    bool active = false, have = false, exhausted = false, any_hit = false;
+    Feed feed(n_rays);
+    unsigned ray_idx = 0;
+    int sp = 0;
+    float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;  // world ray
+    float wix = 0, wiy = 0, wiz = 0;                             // 1 / direction
+    float onx = 0, ony = 0, onz = 0, ofx = 0, ofy = 0, ofz = 0;  // origin as near / far planes see it (padding)
+    LaneHit best;
+    best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
+    float second_t = RT_INF, abs_slack = 0.0f;
+    float best_gate = 0.0f;  // for the closest hit: the larger entry distance of its parent box and its scene leaf box
+    unsigned ref = 0;
+    float tn = 0;
+
+    for(;;) {
+        {
+            unsigned idx = 0;
+            if(feed.take(!active, next_ray, n_rays, idx)) {
+                float o[3], d[3];
+                bool ah = false;
+                if(src.load(idx, o, d, ah)) {
+                    ray_idx = idx;
+                    any_hit = ah;
+                    wox = o[0]; woy = o[1]; woz = o[2];
+                    wdx = d[0]; wdy = d[1]; wdz = d[2];
+                    wix = fast_rcp(wdx); wiy = fast_rcp(wdy); wiz = fast_rcp(wdz);
+                    const float o1 = fabsf(wox) + fabsf(woy) + fabsf(woz);
+                    const float pad = sc.flat_pad * (o1 + sc.flat_reach);
+                    onx = wox + copysignf(pad, wdx); ofx = wox - copysignf(pad, wdx);
+                    ony = woy + copysignf(pad, wdy); ofy = woy - copysignf(pad, wdy);
+                    onz = woz + copysignf(pad, wdz); ofz = woz - copysignf(pad, wdz);
+                    best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
+                    second_t = RT_INF;
+                    abs_slack = 1e-6f * (o1 + sc.hdr.extent);
+                    active = true;
+                    sp = 0;
+                    tn = 0.0f;
+                    // a NaN component: a certain miss (trace_core.h); an infinite origin: every triangle
+                    // test of the reference computes NaN distances and fails
+                    have = !ray_has_nan(o, d) && o1 < 3e38f;
+                    ref = sc.flat_root_ref;
+                }
+            }
+            exhausted = feed.dry;
+        }
+        if(!__any(active)) {
+            if(__all(exhausted)) break;
+            continue;
+        }
+        const bool drained = __any(exhausted);
+
+        for(;;) {
+            const float prune_t = best.t * 1.001f + 8.0f * abs_slack;
+            if(active && !have) {
+                if(sp > 0) {
+                    --sp;
+                    const uint2 e = sp < FAST_LDS_STACK ? s_stack[sp * FAST_BLOCK + tid]
+                                                        : sc.spill[(size_t)(sp - FAST_LDS_STACK) * nthreads + gtid];
+                    ref = e.x;
+                    tn = __uint_as_float(e.y);
+                    have = !(tn > prune_t);
+                } else {
+                    // (the same decision as at the end of a ray in trace_ordered)
+                    const bool odd = best_gate > best.t * 1.0005f + 4.0f * abs_slack;
+                    const bool ambiguous = !any_hit && best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f);
+                    if(ambiguous && odd) best.t = RT_INF;
+                    sink.store(ray_idx, best, ambiguous);
+                    active = false;
+                }
+            }
+            const int nact = __popcll(__ballot(active));
+            if(nact == 0) break;
+            if(!drained && nact < REFILL_BELOW) break;
+
+            // wide nodes always; triangle leaves once enough lanes hold one (or few hold a node)
+            const bool is_leaf = have && (ref >> 30) == REF_TRIANGLE;
+            const bool is_inner = have && !is_leaf;
+            const bool pair = is_leaf && (ref & REF_PAIR) != 0u;
+            const unsigned idx = is_leaf ? (ref & REF_SLOT_MASK) : (ref & REF_INDEX_MASK);
+            const int n_inner = __popcll(__ballot(is_inner));
+            const bool serve_leaf = n_inner < SERVE_ALL_BELOW || __popcll(__ballot(is_leaf)) >= LEAF_BATCH;
+            const bool go = is_inner || (is_leaf && serve_leaf);
+
+            float4 q0, q1, q2, q3, q4, q5, q6;
+            unsigned inst = 0;
+            if(go) {
+                const char *base = sc.flat_buf + ((size_t)idx << 6);
+                const float4 *rp = reinterpret_cast<const float4 *>(base);
+                q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3];
+                if(is_leaf) {
+                    q4 = rp[4]; q5 = rp[5]; q6 = rp[6];
+                    inst = *reinterpret_cast<const unsigned *>(base + 112);
+                }
+            }
+
+            auto push = [&](unsigned r, unsigned key) {
+                const uint2 e = make_uint2(r, key);
+                if(sp < FAST_LDS_STACK) {
+                    s_stack[sp * FAST_BLOCK + tid] = e;
+                    ++sp;
+                } else if(sp - FAST_LDS_STACK < sc.spill_depth) {
+                    sc.spill[(size_t)(sp - FAST_LDS_STACK) * nthreads + gtid] = e;
+                    ++sp;
+                } else {
+                    *sc.error_flag = 1u;
+                }
+            };
+            if(is_inner) {
+                // a QNode, decoded as in trace_ordered; near planes against the origin moved forwards by
+                // the padding, far planes against the origin moved backwards
+                float t0, t1, t2, t3, x0, x1, x2, x3;
+                const float sx = q0.w, sy = q1.x, sz = q1.y;
+                const unsigned lx = __float_as_uint(q2.z), ly = __float_as_uint(q2.w), lz = __float_as_uint(q3.x);
+                const unsigned hx = __float_as_uint(q3.y), hy = __float_as_uint(q3.z), hz = __float_as_uint(q3.w);
+                const bool ngx = (int)__float_as_uint(wix) < 0, ngy = (int)__float_as_uint(wiy) < 0, ngz = (int)__float_as_uint(wiz) < 0;
+                const unsigned nx = ngx ? hx : lx, fx = ngx ? lx : hx;
+                const unsigned ny = ngy ? hy : ly, fy = ngy ? ly : hy;
+                const unsigned nz = ngz ? hz : lz, fz = ngz ? lz : hz;
+#define RT_Q(packed, i, scale, org, o, inv) ((__builtin_fmaf((float)(((packed) >> (8 * (i))) & 0xFFu), scale, org) - (o)) * (inv))
+#define RT_QBOX(i, T_IN, T_OUT)                                                                                              \
+    T_IN = fmaxf(0.0f, fmaxf(fmaxf(RT_Q(nx, i, sx, q0.x, onx, wix), RT_Q(ny, i, sy, q0.y, ony, wiy)), RT_Q(nz, i, sz, q0.z, onz, wiz))); \
+    T_OUT = fminf(RT_INF, fminf(fminf(RT_Q(fx, i, sx, q0.x, ofx, wix), RT_Q(fy, i, sy, q0.y, ofy, wiy)), RT_Q(fz, i, sz, q0.z, ofz, wiz)))
+                RT_QBOX(0, t0, x0);
+                RT_QBOX(1, t1, x1);
+                RT_QBOX(2, t2, x2);
+                RT_QBOX(3, t3, x3);
+#undef RT_QBOX
+#undef RT_Q
+                unsigned r0 = __float_as_uint(q1.z), r1 = __float_as_uint(q1.w), r2 = __float_as_uint(q2.x), r3 = __float_as_uint(q2.y);
+                unsigned k0 = relaxed_pass(t0, x0) && t0 <= prune_t ? __float_as_uint(t0) : 0xFFFFFFFFu;
+                unsigned k1 = relaxed_pass(t1, x1) && t1 <= prune_t ? __float_as_uint(t1) : 0xFFFFFFFFu;
+                unsigned k2 = r2 != REF_NONE && relaxed_pass(t2, x2) && t2 <= prune_t ? __float_as_uint(t2) : 0xFFFFFFFFu;
+                unsigned k3 = r3 != REF_NONE && relaxed_pass(t3, x3) && t3 <= prune_t ? __float_as_uint(t3) : 0xFFFFFFFFu;
+                auto order = [](unsigned &ka, unsigned &ra, unsigned &kb, unsigned &rb) {
+                    const bool sw = kb < ka;
+                    const unsigned kl = sw ? kb : ka, kh = sw ? ka : kb, rl = sw ? rb : ra, rh = sw ? ra : rb;
+                    ka = kl; kb = kh; ra = rl; rb = rh;
+                };
+                order(k0, r0, k1, r1);
+                order(k2, r2, k3, r3);
+                order(k0, r0, k2, r2);
+                order(k1, r1, k3, r3);
+                order(k1, r1, k2, r2);
+                if(k0 == 0xFFFFFFFFu) {
+                    have = false;
+                } else {
+                    if(k3 != 0xFFFFFFFFu) push(r3, k3);
+                    if(k2 != 0xFFFFFFFFu) push(r2, k2);
+                    if(k1 != 0xFFFFFFFFu) push(r1, k1);
+                    ref = r0;
+                    tn = __uint_as_float(k0);
+                }
+            } else if(serve_leaf && is_leaf) {
+                // FlatLeaf: q0, q1.xy parent box; v0, e1, e2, triangle index; q4..q6 rows of world-to-local.
+                // The first leaf of a pair hands over to the second one, two slots on.
+                have = pair;
+                if(pair) ref = (REF_TRIANGLE << 30) | (idx + 2u);
+                // the ray in the instance's space, as the reference forms it (pathtracing.glsl:279-281;
+                // the same expressions as the instance entry of trace_ordered)
+                const float lox = (q4.x * wox + q4.y * woy) + (q4.z * woz + q4.w);
+                const float loy = (q5.x * wox + q5.y * woy) + (q5.z * woz + q5.w);
+                const float loz = (q6.x * wox + q6.y * woy) + (q6.z * woz + q6.w);
+                const float ldx = (q4.x * wdx + q4.y * wdy) + q4.z * wdz;
+                const float ldy = (q5.x * wdx + q5.y * wdy) + q5.z * wdz;
+                const float ldz = (q6.x * wdx + q6.y * wdy) + q6.z * wdz;
+                const float v0x = q1.z, v0y = q1.w, v0z = q2.x, e1x = q2.y, e1y = q2.z, e1z = q2.w, e2x = q3.x, e2y = q3.y, e2z = q3.z;
+                // intersect_triangle, shader/pathtracing.glsl:224-249
+                const float sx = lox - v0x, sy = loy - v0y, sz = loz - v0z;
+                const float s1x = ldy * e2z - e2y * ldz, s1y = ldz * e2x - e2z * ldx, s1z = ldx * e2y - e2x * ldy;
+                const float s2x = sy * e1z - e1y * sz, s2y = sz * e1x - e1z * sx, s2z = sx * e1y - e1x * sy;
+                const float k = 1.0f / (s1x * e1x + s1y * e1y + s1z * e1z);
+                const float t = (s2x * e2x + s2y * e2y + s2z * e2z) * k;
+                const float u = (s1x * sx + s1y * sy + s1z * sz) * k;
+                const float v = (s2x * ldx + s2y * ldy + s2z * ldz) * k;
+                if(RT_RAY_MINDIS <= t && 0.0f <= u && 0.0f <= v && u + v <= 1.0f) {
+                    if(t < best.t) {
+                        // a candidate only if the reference would have reached this leaf: its parent's box in
+                        // the instance's space and the instance's scene leaf box in world space, exactly
+                        float te, tw = 0.0f;
+                        bool pass = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, lox, loy, loz, ldx, ldy, ldz, te);
+                        if(pass) {
+                            const float4 *ip = reinterpret_cast<const float4 *>(sc.scene_buf + ((size_t)(sc.hdr.inst_base + 2u * inst) << 6));
+                            const float4 b5 = ip[5], b6 = ip[6];
+                            pass = slab_test(b5.z, b5.w, b6.x, b6.y, b6.z, b6.w, wox, woy, woz, wdx, wdy, wdz, tw);
+                        }
+                        if(pass) {
+                            second_t = fminf(second_t, best.t);
+                            best.t = t; best.u = u; best.v = v;
+                            best.tri = __float_as_int(q3.w);
+                            best.inst = (int)inst;
+                            best_gate = fmaxf(te, tw);
+                            if(any_hit) {
+                                sp = 0;
+                                have = false;
+                            }
+                        }
+                    } else {
+                        second_t = fminf(second_t, t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace rta

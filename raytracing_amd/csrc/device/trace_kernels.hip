@@ -6,6 +6,7 @@
 #include "path_state_io.h"
 #include "shade_vertex.h"
 #include "trace_fast.h"
+#include "trace_flat.h"
 
 namespace rta {
 namespace {
@@ -16,6 +17,15 @@ namespace {
 #define RT_FAST_WAVES 4
 #endif
 #define RT_FAST_OCC __attribute__((amdgpu_waves_per_eu(RT_FAST_WAVES)))
+
+// MODE of the ordered kernels: 0 = two levels with WNodes, 1 = two levels with QNodes, 2 = the flattened tree
+template <int MODE, class Source, class Sink>
+__device__ __forceinline__ void trace_fast_any(const FastScene &sc, Source &src, Sink &sink, unsigned *next_ray, unsigned n_rays,
+                                               uint2 *s_stack) {
+    if constexpr(MODE == 2) trace_flat(sc, src, sink, next_ray, n_rays, s_stack);
+    else trace_ordered<MODE == 1>(sc, src, sink, next_ray, n_rays, s_stack);
+}
+#define RT_PICK_FAST(kernel) (sc.flat_buf ? kernel<2> : (sc.hdr.quantised ? kernel<1> : kernel<0>))
 
 // ---- stand-alone closest hit -----------------------------------------------------------
 // `redo`, when given, lists the ray indices to trace (the ordered kernel's undecided rays).
@@ -72,14 +82,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void intersect_kernel(TraceScene sc, c
     else trace_persistent(sc, src, sink, next_counter, n, s_stack);
 }
 
-template <bool QUANT>
+template <int MODE>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void intersect_fast_kernel(FastScene sc, const float *rays, unsigned n,
                                                                     pt_hit *hits, unsigned *next_counter,
                                                                     unsigned *redo, unsigned *redo_count) {
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
     RaySource src{rays, nullptr, nullptr};
     HitSinkFast sink{hits, redo, redo_count};
-    trace_ordered<QUANT>(sc, src, sink, next_counter, n, s_stack);
+    trace_fast_any<MODE>(sc, src, sink, next_counter, n, s_stack);
 }
 
 // ---- extend ------------------------------------------------------------------------------
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void extend_kernel(TraceScene sc, cons
     else trace_persistent(sc, src, sink, next_counter, *count, s_stack);
 }
 
-template <bool QUANT>
+template <int MODE>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_fast_kernel(FastScene sc, const unsigned *queue,
                                                                  const unsigned *count, const PathRay *rays,
                                                                  PathHit *hits, unsigned *next_counter,
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_fast_kernel(Fas
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
     ExtendSource src{queue, rays, nullptr};
     ExtendSinkFast sink{queue, hits, redo, redo_count};
-    trace_ordered<QUANT>(sc, src, sink, next_counter, *count, s_stack);
+    trace_fast_any<MODE>(sc, src, sink, next_counter, *count, s_stack);
 }
 
 // ---- primary rays: generate + extend(0) in one launch --------------------------------------------
@@ -161,7 +171,7 @@ struct PrimarySource {
     }
 };
 
-template <bool QUANT>
+template <int MODE>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_fast_kernel(FastScene sc, DrawParams dp, unsigned *next_counter,
                                                                   unsigned *redo, unsigned *redo_count) {
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_fast_kernel(Fa
     }
     PrimarySource src{dp};
     ExtendSinkFast sink{nullptr, dp.hits, redo, redo_count};
-    trace_ordered<QUANT>(sc, src, sink, next_counter, (unsigned)dp.npix, s_stack);
+    trace_fast_any<MODE>(sc, src, sink, next_counter, (unsigned)dp.npix, s_stack);
 }
 
 // ---- shadow ------------------------------------------------------------------------------
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void shadow_kernel(TraceScene sc, cons
 }
 
 // sky-only form (n_shadow == 1): every query is an occlusion query
-template <bool QUANT>
+template <int MODE>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_fast_kernel(FastScene sc, const unsigned *queue,
                                                                  const unsigned *count, const PathRay *rays,
                                                                  ShadowEntry *shadow, int npix,
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_fast_kernel(Fas
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
     ShadowSource src{queue, rays, shadow, 1, npix};
     ShadowSink sink{queue, shadow, 1, npix};
-    trace_ordered<QUANT>(sc, src, sink, next_counter, *count, s_stack);
+    trace_fast_any<MODE>(sc, src, sink, next_counter, *count, s_stack);
 }
 
 // ---- shadow rays of vertex d and extend rays of vertex d+1 in ONE launch ---------------------
@@ -273,7 +283,7 @@ struct PathSink {
     }
 };
 
-template <bool QUANT>
+template <int MODE>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel(
     FastScene sc, const unsigned *queue_e, const unsigned *count_e, const unsigned *queue_s, const unsigned *count_s,
     const PathRay *rays, PathHit *hits, ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo,
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel
     if(blockIdx.x == 0 && threadIdx.x == 0 && n_s) atomicAdd(shadow_rays_stat, (unsigned long long)n_s);
     PathSource src{ExtendSource{queue_e, rays, nullptr}, ShadowSource{queue_s, rays, shadow, 1, npix}, n_e};
     PathSink sink{ExtendSinkFast{queue_e, hits, redo, redo_count}, ShadowApplySink{queue_s, shadow, thr, acc}, n_e};
-    trace_ordered<QUANT>(sc, src, sink, next_counter, n_e + n_s, s_stack);
+    trace_fast_any<MODE>(sc, src, sink, next_counter, n_e + n_s, s_stack);
 }
 
 }  // namespace
@@ -292,13 +302,13 @@ void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, cons
                             const unsigned *queue_s, const unsigned *count_s, const PathRay *rays, PathHit *hits,
                             ShadowEntry *shadow, int npix, unsigned *next_counter, unsigned *redo, unsigned *redo_count,
                             const PathThroughput *thr, PathAccum *acc, unsigned long long *shadow_rays_stat) {
-    hipLaunchKernelGGL(sc.hdr.quantised ? path_trace_fast_kernel<true> : path_trace_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue_e, count_e, queue_s, count_s, rays,
+    hipLaunchKernelGGL(RT_PICK_FAST(path_trace_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue_e, count_e, queue_s, count_s, rays,
                        hits, shadow, npix, next_counter, redo, redo_count, thr, acc, shadow_rays_stat);
 }
 
 void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter, unsigned *redo,
                          unsigned *redo_count) {
-    hipLaunchKernelGGL(sc.hdr.quantised ? primary_fast_kernel<true> : primary_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp,
+    hipLaunchKernelGGL(RT_PICK_FAST(primary_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp,
                        next_counter, redo, redo_count);
 }
 
@@ -311,7 +321,7 @@ void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const flo
 
 void launch_intersect_fast(hipStream_t s, const FastScene &sc, int blocks, const float *rays, unsigned n,
                            pt_hit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count) {
-    hipLaunchKernelGGL(sc.hdr.quantised ? intersect_fast_kernel<true> : intersect_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, rays, n, hits, next_counter,
+    hipLaunchKernelGGL(RT_PICK_FAST(intersect_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, rays, n, hits, next_counter,
                        redo, redo_count);
 }
 
@@ -324,7 +334,7 @@ void launch_extend(hipStream_t s, const TraceScene &sc, int blocks, const unsign
 void launch_extend_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                         const PathRay *rays, PathHit *hits, unsigned *next_counter, unsigned *redo,
                         unsigned *redo_count) {
-    hipLaunchKernelGGL(sc.hdr.quantised ? extend_fast_kernel<true> : extend_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, hits,
+    hipLaunchKernelGGL(RT_PICK_FAST(extend_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, hits,
                        next_counter, redo, redo_count);
 }
 
@@ -336,7 +346,7 @@ void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsign
 
 void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                         const PathRay *rays, ShadowEntry *shadow, int npix, unsigned *next_counter) {
-    hipLaunchKernelGGL(sc.hdr.quantised ? shadow_fast_kernel<true> : shadow_fast_kernel<false>, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, shadow, npix,
+    hipLaunchKernelGGL(RT_PICK_FAST(shadow_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, shadow, npix,
                        next_counter);
 }
 

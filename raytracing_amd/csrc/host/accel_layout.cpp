@@ -1,4 +1,5 @@
 #include "accel_layout.h"
+#include "bvh_builder.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -8,6 +9,7 @@
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 
 namespace rta {
 namespace {
@@ -740,6 +742,233 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
     return true;
 }
 
+bool build_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const TriangleRec *tris, size_t n_tris,
+                      const BVHNodeInfo *scene, size_t n_scene_nodes, const InstanceInfo *inst, size_t n_inst,
+                      size_t max_leaves, bool only_axis_aligned, int n_threads, AccelFlat &out, std::string &why_not) {
+    out = AccelFlat();
+    // ---- leaves under every distinct mesh root (counted first: instancing can multiply them beyond any memory)
+    std::vector<int32_t> root_ids;
+    for(size_t i = 0; i < n_inst; i++) root_ids.push_back(inst[i].meshIndex);
+    std::sort(root_ids.begin(), root_ids.end());
+    root_ids.erase(std::unique(root_ids.begin(), root_ids.end()), root_ids.end());
+    struct MeshLeaf { int32_t node, parent; };
+    std::vector<std::vector<MeshLeaf>> leaves_of(root_ids.size());
+    {
+        size_t visited = 0;
+        std::vector<MeshLeaf> stack;
+        for(size_t r = 0; r < root_ids.size(); r++) {
+            stack.push_back({root_ids[r], -1});
+            while(!stack.empty()) {
+                const MeshLeaf e = stack.back();
+                stack.pop_back();
+                if(++visited > 4 * n_mesh_nodes + 16) {  // (shared subtrees walked over and over: not a forest worth flattening)
+                    why_not = "the mesh trees share subtrees";
+                    return false;
+                }
+                if(mesh[e.node].triangleIndex >= 0) {
+                    leaves_of[r].push_back(e);
+                } else {
+                    stack.push_back({mesh[e.node].rsIndex, e.node});
+                    stack.push_back({mesh[e.node].lsIndex, e.node});
+                }
+            }
+        }
+    }
+    size_t n = 0;
+    std::vector<size_t> first(n_inst + 1, 0);
+    std::vector<uint32_t> root_of(n_inst);
+    for(size_t i = 0; i < n_inst; i++) {
+        root_of[i] = (uint32_t)(std::lower_bound(root_ids.begin(), root_ids.end(), inst[i].meshIndex) - root_ids.begin());
+        n += leaves_of[root_of[i]].size();
+        first[i + 1] = n;
+        if(n > max_leaves) {
+            why_not = "more than " + std::to_string(max_leaves) + " triangles once every instance is counted";
+            return false;
+        }
+    }
+    if(n == 0 || 3 * (uint64_t)n >= REF_SLOT_MASK) {
+        why_not = "too many leaves for 29-bit slots";
+        return false;
+    }
+    // ---- per instance: A = inverse of the affine world-to-local matrix (double), cond = || |A| |W| ||
+    struct Affine { double a[3][4]; };
+    std::vector<Affine> to_world(n_inst);
+    double cond_max = 1.0;
+    for(size_t i = 0; i < n_inst; i++) {
+        const float *m = inst[i].world2local;  // column major: W[r][c] = m[c * 4 + r]
+        double w[3][4];
+        for(int r = 0; r < 3; r++)
+            for(int c = 0; c < 4; c++) {
+                w[r][c] = m[c * 4 + r];
+                if(!std::isfinite(w[r][c])) {
+                    why_not = "instance " + std::to_string(i) + ": matrix is not finite";
+                    return false;
+                }
+            }
+        if(only_axis_aligned)
+            for(int r = 0; r < 3; r++) {
+                double big = 0.0, sum = 0.0;
+                for(int c = 0; c < 3; c++) {
+                    big = std::max(big, std::fabs(w[r][c]));
+                    sum += std::fabs(w[r][c]);
+                }
+                if(sum - big > 1e-3 * big) {
+                    why_not = "instance " + std::to_string(i) + " is rotated off the axes: the world boxes of its triangles' parent boxes would be loose";
+                    return false;
+                }
+            }
+        const double det = w[0][0] * (w[1][1] * w[2][2] - w[1][2] * w[2][1]) - w[0][1] * (w[1][0] * w[2][2] - w[1][2] * w[2][0]) +
+                           w[0][2] * (w[1][0] * w[2][1] - w[1][1] * w[2][0]);
+        if(!(std::fabs(det) > 0.0) || !std::isfinite(1.0 / det)) {
+            why_not = "instance " + std::to_string(i) + ": matrix is singular";
+            return false;
+        }
+        Affine &A = to_world[i];
+        const double id = 1.0 / det;
+        A.a[0][0] = (w[1][1] * w[2][2] - w[1][2] * w[2][1]) * id;
+        A.a[0][1] = (w[0][2] * w[2][1] - w[0][1] * w[2][2]) * id;
+        A.a[0][2] = (w[0][1] * w[1][2] - w[0][2] * w[1][1]) * id;
+        A.a[1][0] = (w[1][2] * w[2][0] - w[1][0] * w[2][2]) * id;
+        A.a[1][1] = (w[0][0] * w[2][2] - w[0][2] * w[2][0]) * id;
+        A.a[1][2] = (w[0][2] * w[1][0] - w[0][0] * w[1][2]) * id;
+        A.a[2][0] = (w[1][0] * w[2][1] - w[1][1] * w[2][0]) * id;
+        A.a[2][1] = (w[0][1] * w[2][0] - w[0][0] * w[2][1]) * id;
+        A.a[2][2] = (w[0][0] * w[1][1] - w[0][1] * w[1][0]) * id;
+        for(int r = 0; r < 3; r++) A.a[r][3] = -(A.a[r][0] * w[0][3] + A.a[r][1] * w[1][3] + A.a[r][2] * w[2][3]);
+        double cond = 0.0;
+        for(int r = 0; r < 3; r++) {
+            double row = 0.0;
+            for(int c = 0; c < 3; c++)
+                for(int k = 0; k < 3; k++) row += std::fabs(A.a[r][k]) * std::fabs(w[k][c]);
+            cond = std::max(cond, row);
+        }
+        if(!(cond <= 256.0)) {
+            why_not = "instance " + std::to_string(i) + ": matrix is badly conditioned";
+            return false;
+        }
+        cond_max = std::max(cond_max, cond);
+    }
+    // scene leaf boxes (what an instance whose mesh is one triangle is bounded by)
+    std::vector<const BVHNodeInfo *> scene_leaf(n_inst, nullptr);
+    for(size_t k = 0; k < n_scene_nodes; k++)
+        if(scene[k].instanceIndex >= 0 && (size_t)scene[k].instanceIndex < n_inst) scene_leaf[scene[k].instanceIndex] = &scene[k];
+    // ---- world boxes of the leaves: the eight corners of the reference parent box under A, rounded outwards
+    std::vector<Box> boxes(n);
+    std::vector<uint8_t> bad(n_inst, 0);
+    const unsigned threads = n_threads > 0 ? (unsigned)n_threads : layout_threads();
+    parallel_items(n_inst, threads, [&](size_t i) {
+        const std::vector<MeshLeaf> &lv = leaves_of[root_of[i]];
+        const Affine &A = to_world[i];
+        for(size_t j = 0; j < lv.size(); j++) {
+            Box &b = boxes[first[i] + j];
+            if(lv[j].parent < 0) {
+                if(!scene_leaf[i]) { bad[i] = 1; return; }
+                for(int k = 0; k < 3; k++) { b.mi[k] = scene_leaf[i]->aa[k]; b.mx[k] = scene_leaf[i]->bb[k]; }
+            } else {
+                const BVHNodeInfo &pn = mesh[lv[j].parent];
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for(int corner = 0; corner < 8; corner++) {
+                    const double x = corner & 1 ? pn.bb[0] : pn.aa[0], y = corner & 2 ? pn.bb[1] : pn.aa[1], z = corner & 4 ? pn.bb[2] : pn.aa[2];
+                    for(int r = 0; r < 3; r++) {
+                        const double v = A.a[r][0] * x + A.a[r][1] * y + A.a[r][2] * z + A.a[r][3];
+                        lo[r] = std::min(lo[r], v);
+                        hi[r] = std::max(hi[r], v);
+                    }
+                }
+                for(int k = 0; k < 3; k++) {
+                    // (the double sums carry errors far below one float step: one more step outwards covers them)
+                    b.mi[k] = std::nextafterf(std::nextafterf((float)lo[k], -INFINITY), -INFINITY);
+                    b.mx[k] = std::nextafterf(std::nextafterf((float)hi[k], INFINITY), INFINITY);
+                }
+            }
+            for(int k = 0; k < 3; k++)
+                if(!std::isfinite(b.mi[k]) || !std::isfinite(b.mx[k]) || std::fabs(b.mi[k]) > 1e17f || std::fabs(b.mx[k]) > 1e17f) { bad[i] = 1; return; }
+        }
+    });
+    for(size_t i = 0; i < n_inst; i++)
+        if(bad[i]) {
+            why_not = "instance " + std::to_string(i) + ": a box is not finite";
+            return false;
+        }
+    // ---- one SAH tree over them, then four-wide
+    SahTree tree;
+    // (built over the boxes the traversal will cull with: a leaf whose reference sibling is a subtree has a parent
+    // box several times its own size, and a tree shaped by the triangles' own boxes instead, then re-fitted,
+    // measured 12 % slower on the demo scene -- such leaves belong high in the tree)
+    build_sah_tree(boxes.data(), (int)n, tree, (int)threads);
+    std::vector<Box>().swap(boxes);
+    const size_t n_nodes = tree.nodes.size();
+    std::vector<BVHNodeInfo> nodes(n_nodes);
+    std::vector<uint32_t> leaf_slot(n_nodes, 0);
+    uint32_t n_leaf_seen = 0;
+    for(size_t k = 0; k < n_nodes; k++) {  // (children come after their parents; leaves numbered in that order)
+        const SahNode &sn = tree.nodes[k];
+        BVHNodeInfo &b = nodes[k];
+        for(int a = 0; a < 3; a++) { b.aa[a] = sn.box.mi[a]; b.bb[a] = sn.box.mx[a]; }
+        b.aa[3] = b.bb[3] = 0.0f;
+        b.lsIndex = sn.left;
+        b.rsIndex = sn.right;
+        b.instanceIndex = -1;
+        b.triangleIndex = sn.prim;
+        if(sn.prim >= 0) leaf_slot[k] = 2u * n_leaf_seen++;
+    }
+    if(tree.root != 0 || n_leaf_seen != n) {
+        why_not = "internal: unexpected tree shape";
+        return false;
+    }
+    std::vector<SahNode>().swap(tree.nodes);
+    std::vector<uint32_t> wide_of;
+    std::vector<uint8_t> wide_height;
+    const uint32_t wide_base = 2u * (uint32_t)n;
+    const uint32_t end = build_wide_nodes(
+        nodes.data(), n_nodes, std::vector<int32_t>{0}, true, true, [&](int32_t c) { return nodes[c].triangleIndex >= 0; },
+        [&](int32_t c) { return make_ref(REF_TRIANGLE, leaf_slot[c]); }, false, REF_MESH_INNER, wide_base, true, out.slots, wide_of,
+        wide_height);
+    if(end == REF_NONE || end > REF_SLOT_MASK) {
+        why_not = "too many leaves for 29-bit slots";
+        return false;
+    }
+    out.root_ref = n == 1 ? make_ref(REF_TRIANGLE, 0) : make_ref(REF_MESH_INNER, wide_of[0]);
+    out.max_stack = 3 * (wide_height.empty() ? 0 : wide_height[0]) + 2;
+    out.n_leaves = n;
+    // ---- the leaf records
+    std::vector<size_t> entry_first = first;
+    parallel_items((n_nodes + 65535) / 65536, threads, [&](size_t ch) {
+        const size_t lo = ch * 65536, hi = std::min(n_nodes, lo + 65536);
+        for(size_t k = lo; k < hi; k++) {
+            if(nodes[k].triangleIndex < 0) continue;
+            const size_t e = (size_t)nodes[k].triangleIndex;  // leaf number in (instance, leaf of its mesh) order
+            const size_t i = (size_t)(std::upper_bound(entry_first.begin(), entry_first.end(), e) - entry_first.begin()) - 1;
+            const MeshLeaf &ml = leaves_of[root_of[i]][e - entry_first[i]];
+            FlatLeaf &l = *reinterpret_cast<FlatLeaf *>(&out.slots[leaf_slot[k]]);
+            memset(&l, 0, sizeof l);
+            const float inf = std::numeric_limits<float>::infinity();
+            const float *v = tris[mesh[ml.node].triangleIndex].ver;
+            for(int a = 0; a < 3; a++) {
+                l.parent_lo[a] = ml.parent < 0 ? -inf : mesh[ml.parent].aa[a];
+                l.parent_hi[a] = ml.parent < 0 ? inf : mesh[ml.parent].bb[a];
+                l.v0[a] = v[a];
+                l.e1[a] = v[3 + a] - v[a];
+                l.e2[a] = v[6 + a] - v[a];
+            }
+            l.triangle = (uint32_t)mesh[ml.node].triangleIndex;
+            for(int r = 0; r < 3; r++)
+                for(int c = 0; c < 4; c++) l.row[r][c] = inst[i].world2local[c * 4 + r];
+            l.instance = (uint32_t)i;
+        }
+    });
+    (void)n_tris;
+    out.pad = (float)(64.0 * 5.9604644775390625e-8 * cond_max);
+    double reach = 0.0;
+    for(int a = 0; a < 3; a++) reach += std::max(std::fabs((double)scene[0].aa[a]), std::fabs((double)scene[0].bb[a]));
+    out.reach = (float)reach;
+    if(!std::isfinite(out.reach)) {
+        why_not = "the scene box is not finite";
+        return false;
+    }
+    return true;
+}
+
 namespace {
 
 // Child i of the wide node at `rec` as the ordered traversal sees it: reference and box
@@ -971,6 +1200,176 @@ bool verify_accel_levels(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const Acc
         err = "max_stack " + std::to_string(sl.max_stack) + " is below the deepest walk " + std::to_string(deepest_mesh + deepest_scene);
         return false;
     }
+    return true;
+}
+
+bool verify_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const TriangleRec *tris, const InstanceInfo *inst, size_t n_inst,
+                       const AccelFlat &fl, uint64_t counts[4], std::string &err) {
+    for(int k = 0; k < 4; k++) counts[k] = 0;
+    const size_t n_slots = fl.slots.size(), n = fl.n_leaves;
+    if(n == 0 || n_slots < 2 * n) {
+        err = "the flat tree no longer holds its slots";
+        return false;
+    }
+    // what must be there: every (instance, triangle) once, with the triangle's reference parent
+    struct Want { uint64_t key; int32_t parent; };
+    std::vector<Want> want;
+    for(size_t i = 0; i < n_inst; i++) {
+        std::vector<std::pair<int32_t, int32_t>> work{{inst[i].meshIndex, -1}};
+        while(!work.empty()) {
+            const auto e = work.back();
+            work.pop_back();
+            if(e.first < 0 || (size_t)e.first >= n_mesh_nodes) {
+                err = "mesh node out of range";
+                return false;
+            }
+            if(mesh[e.first].triangleIndex >= 0) {
+                want.push_back({((uint64_t)i << 32) | (uint32_t)mesh[e.first].triangleIndex, e.second});
+            } else {
+                work.push_back({mesh[e.first].lsIndex, e.first});
+                work.push_back({mesh[e.first].rsIndex, e.first});
+            }
+        }
+    }
+    std::sort(want.begin(), want.end(), [](const Want &a, const Want &b) { return a.key < b.key; });
+    if(want.size() != n) {
+        err = "the flat tree holds " + std::to_string(n) + " leaves, the scene has " + std::to_string(want.size());
+        return false;
+    }
+    // world box of a leaf, from its own record: corners of the parent box through the inverse of its rows
+    auto leaf_box = [&](const FlatLeaf &l, float lo[3], float hi[3]) {
+        long double w[3][4], a[3][3];
+        for(int r = 0; r < 3; r++)
+            for(int c = 0; c < 4; c++) w[r][c] = l.row[r][c];
+        const long double det = w[0][0] * (w[1][1] * w[2][2] - w[1][2] * w[2][1]) - w[0][1] * (w[1][0] * w[2][2] - w[1][2] * w[2][0]) +
+                                w[0][2] * (w[1][0] * w[2][1] - w[1][1] * w[2][0]);
+        for(int r = 0; r < 3; r++)
+            for(int c = 0; c < 3; c++) {
+                // cofactor of w[c][r] over det
+                const int r1 = (c + 1) % 3, r2 = (c + 2) % 3, c1 = (r + 1) % 3, c2 = (r + 2) % 3;
+                a[r][c] = (w[r1][c1] * w[r2][c2] - w[r1][c2] * w[r2][c1]) / det;
+            }
+        for(int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; }
+        for(int corner = 0; corner < 8; corner++) {
+            const long double p[3] = {(corner & 1 ? l.parent_hi[0] : l.parent_lo[0]), (corner & 2 ? l.parent_hi[1] : l.parent_lo[1]),
+                                      (corner & 4 ? l.parent_hi[2] : l.parent_lo[2])};
+            for(int r = 0; r < 3; r++) {
+                const long double v = a[r][0] * (p[0] - w[0][3]) + a[r][1] * (p[1] - w[1][3]) + a[r][2] * (p[2] - w[2][3]);
+                lo[r] = std::min(lo[r], (float)v);
+                hi[r] = std::max(hi[r], (float)v);
+            }
+        }
+    };
+    std::vector<uint8_t> seen(n_slots, 0);
+    std::vector<Want> got;
+    got.reserve(n);
+    uint64_t unbounded = 0;
+    bool ok = true;
+    int deepest = 0;
+    // returns the box of everything under `ref`; depth = wide nodes above it
+    struct Bx { float lo[3], hi[3]; };
+    auto visit_leaf = [&](uint32_t slot, Bx &b) {
+        if(slot + 2 > 2 * n || (slot & 1u) || seen[slot]) {
+            err = "a leaf reference is out of range or names a leaf twice";
+            return false;
+        }
+        seen[slot] = 1;
+        const FlatLeaf &l = *reinterpret_cast<const FlatLeaf *>(&fl.slots[slot]);
+        if(l.instance >= n_inst) {
+            err = "a leaf names an instance out of range";
+            return false;
+        }
+        for(int r = 0; r < 3; r++)
+            for(int c = 0; c < 4; c++)
+                if(memcmp(&l.row[r][c], &inst[l.instance].world2local[c * 4 + r], 4)) {
+                    err = "a leaf's matrix is not its instance's";
+                    return false;
+                }
+        const float *v = tris[l.triangle].ver;
+        for(int k = 0; k < 3; k++)
+            if(l.v0[k] != v[k] || l.e1[k] != v[3 + k] - v[k] || l.e2[k] != v[6 + k] - v[k]) {
+                if(!(std::isnan(v[k]) || std::isnan(v[3 + k]) || std::isnan(v[6 + k]))) {
+                    err = "a leaf's triangle is not the one it names";
+                    return false;
+                }
+            }
+        got.push_back({((uint64_t)l.instance << 32) | l.triangle, 0});
+        if(std::isinf(l.parent_lo[0])) {  // a one-triangle mesh: bounded by the instance's scene leaf box, not checked here
+            for(int k = 0; k < 3; k++) { b.lo[k] = std::numeric_limits<float>::infinity(); b.hi[k] = -b.lo[k]; }
+        } else {
+            leaf_box(l, b.lo, b.hi);
+        }
+        return true;
+    };
+    struct Rec {
+        static bool walk(uint32_t ref, int depth, Bx &out, const AccelFlat &fl, size_t n, size_t n_slots, uint64_t counts[4], uint64_t &unbounded,
+                         int &deepest, std::string &err, const std::function<bool(uint32_t, Bx &)> &leaf) {
+            if((ref >> 30) == REF_TRIANGLE) {
+                const uint32_t slot = ref & REF_SLOT_MASK;
+                if(!leaf(slot, out)) return false;
+                if(ref & REF_PAIR) {
+                    Bx b2;
+                    if(!leaf(slot + 2, b2)) return false;
+                    for(int k = 0; k < 3; k++) { out.lo[k] = std::min(out.lo[k], b2.lo[k]); out.hi[k] = std::max(out.hi[k], b2.hi[k]); }
+                }
+                return true;
+            }
+            const uint32_t slot = ref & REF_INDEX_MASK;
+            if((ref >> 30) != REF_MESH_INNER || slot < 2 * n || slot >= n_slots || depth > 200) {
+                err = "a node reference is out of range";
+                return false;
+            }
+            counts[1]++;
+            deepest = std::max(deepest, depth + 1);
+            for(int k = 0; k < 3; k++) { out.lo[k] = std::numeric_limits<float>::infinity(); out.hi[k] = -out.lo[k]; }
+            for(int i = 0; i < 4; i++) {
+                uint32_t cref;
+                float lo[3], hi[3];
+                decode_child(&fl.slots[slot], true, i, cref, lo, hi);
+                if(cref == REF_NONE) continue;
+                Bx below;
+                if(!walk(cref, depth + 1, below, fl, n, n_slots, counts, unbounded, deepest, err, leaf)) return false;
+                counts[2]++;
+                if(below.lo[0] <= below.hi[0] && !contains(lo, hi, below.lo, below.hi, unbounded)) {
+                    err = "a child box does not contain the leaves below it";
+                    return false;
+                }
+                for(int k = 0; k < 3; k++) { out.lo[k] = std::min(out.lo[k], below.lo[k]); out.hi[k] = std::max(out.hi[k], below.hi[k]); }
+            }
+            return true;
+        }
+    };
+    Bx all;
+    const std::function<bool(uint32_t, Bx &)> leaf_fn = visit_leaf;
+    ok = Rec::walk(fl.root_ref, 0, all, fl, n, n_slots, counts, unbounded, deepest, err, leaf_fn);
+    if(!ok) return false;
+    std::sort(got.begin(), got.end(), [](const Want &a, const Want &b) { return a.key < b.key; });
+    for(size_t k = 0; k < n; k++) {
+        if(got.size() != n || got[k].key != want[k].key) {
+            err = "the flat tree reaches other (instance, triangle) pairs than the scene holds";
+            return false;
+        }
+    }
+    // parent boxes: the reference parent's, bit for bit
+    for(size_t slot = 0; slot < 2 * n; slot += 2) {
+        const FlatLeaf &l = *reinterpret_cast<const FlatLeaf *>(&fl.slots[slot]);
+        const uint64_t key = ((uint64_t)l.instance << 32) | l.triangle;
+        const auto it = std::lower_bound(want.begin(), want.end(), key, [](const Want &a, uint64_t k) { return a.key < k; });
+        const float inf = std::numeric_limits<float>::infinity();
+        for(int k = 0; k < 3; k++) {
+            const float plo = it->parent < 0 ? -inf : mesh[it->parent].aa[k], phi = it->parent < 0 ? inf : mesh[it->parent].bb[k];
+            if(memcmp(&plo, &l.parent_lo[k], 4) || memcmp(&phi, &l.parent_hi[k], 4)) {
+                err = "a leaf's parent box is not its reference parent's";
+                return false;
+            }
+        }
+    }
+    if(3 * deepest > fl.max_stack) {
+        err = "max_stack " + std::to_string(fl.max_stack) + " is below the deepest walk " + std::to_string(3 * deepest);
+        return false;
+    }
+    counts[0] = n;
+    counts[3] = unbounded;
     return true;
 }
 

@@ -55,6 +55,32 @@ bool build_accel_scene_level(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const
                              size_t n_scene_nodes, const InstanceInfo *inst, size_t n_inst, AccelSceneLevel &out,
                              std::string &err, bool *missing_root = nullptr);
 
+// The whole scene as ONE four-wide tree in world space (trace_flat.h): a FlatLeaf per (instance, triangle), two
+// slots each, then QNodes.  Built over the world-space boxes of the leaves' reference parent boxes.
+struct AccelFlat {
+    std::vector<TNode> slots;
+    uint32_t root_ref = REF_NONE;
+    float pad = 0.0f;    // FastScene::flat_pad
+    float reach = 0.0f;  // FastScene::flat_reach
+    int max_stack = 0;
+    size_t n_leaves = 0;
+};
+// Returns false when the scene gets no flat tree -- more than max_leaves (instance, triangle) pairs, a singular or
+// badly conditioned instance matrix, coordinates that are not finite, or (only_axis_aligned) an instance rotated
+// off the axes, whose parent boxes turn into loose world boxes (measured: 20 % slower than the two levels on a
+// scene of randomly rotated meshes, 5 % faster on the axis-aligned demo scene) -- and says why; that is no error: the two
+// levels serve such a scene.  The buffers must have passed build_accel_mesh_level / build_accel_scene_level.
+bool build_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const TriangleRec *tris, size_t n_tris,
+                      const BVHNodeInfo *scene, size_t n_scene_nodes, const InstanceInfo *inst, size_t n_inst,
+                      size_t max_leaves, bool only_axis_aligned, int n_threads, AccelFlat &out, std::string &why_not);
+// Independent check of a flat tree that still holds its slots: it reaches every (instance, triangle) pair of the
+// scene exactly once; a leaf carries its instance's matrix, its triangle and the box of the triangle's reference
+// parent; every child box as the kernel decodes it contains the world boxes (parent box corners through the
+// inverse of the leaf's own matrix, long double) of the leaves below it; max_stack bounds the deepest walk.
+// counts: {leaves, wide nodes, child boxes checked, planes that decode to "unbounded"}.
+bool verify_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const TriangleRec *tris, const InstanceInfo *inst, size_t n_inst,
+                       const AccelFlat &fl, uint64_t counts[4], std::string &err);
+
 // Independent check of the two levels (host only, meant for tests and for debugging a scene
 // the kernels disagree on): every wide tree reaches exactly the triangles / instances its
 // binary tree reaches, every child box as the kernel decodes it contains the reference's box

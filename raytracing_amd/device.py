@@ -240,7 +240,7 @@ class PathTracingPass:
         return dict(samples=int(s.samples), rays_extend=int(s.rays_extend), rays_shadow=int(s.rays_shadow),
                     draws=int(s.draws), rays_retraced=int(s.rays_retraced), mesh_level_builds=int(s.mesh_level_builds),
                     scene_level_builds=int(s.scene_level_builds), debug=[int(x) for x in s.debug],
-                    reference_order_forced=int(s.reference_order_forced))
+                    reference_order_forced=int(s.reference_order_forced), flat_leaves=int(s.flat_leaves))
 
     def prepare(self):
         """Validates the bound scene buffers and builds the traversal arrays now instead of inside the next draw."""

@@ -42,7 +42,7 @@ def test_draw_preconditions(gpu_ctx, casa, small_sky):
     p.set_params(bad)
     fails(p.draw, "lightCount")                 # more lights than the bound buffer holds
     fails(lambda: p.set_pipeline(0), "1..")
-    fails(lambda: p.set_traversal(2), "mode")
+    fails(lambda: p.set_traversal(4), "mode")
     fails(lambda: p.bind_texture("albedoTexture", sb.sky_tex), "unknown sampler")
     p.destroy()
     sb.release()

@@ -154,3 +154,70 @@ def test_a_tree_large_enough_to_be_cut_into_groups(fmt):
     rc, counts, err = check_layout(sd, fmt)
     assert rc == 0, err
     assert counts[2] > len(sd.triangles)
+
+
+def check_flat(sd, only_axis_aligned, mesh_nodes=None, instances=None):
+    mesh_nodes = sd.mesh_nodes if mesh_nodes is None else mesh_nodes
+    instances = sd.instances if instances is None else instances
+    counts = (C.c_uint64 * 4)()
+    why = C.create_string_buffer(256)
+    rc = lib.pt_host_check_flat_layout(mesh_nodes.ctypes.data, len(mesh_nodes), sd.triangles.ctypes.data, len(sd.triangles),
+                                       sd.scene_nodes.ctypes.data, len(sd.scene_nodes), instances.ctypes.data, len(instances),
+                                       1 if only_axis_aligned else 0, counts, why, 256)
+    return rc, [int(c) for c in counts], why.value.decode(), lib.pt_last_error().decode()
+
+
+def test_casa_flat_tree(casa):
+    """The flattened tree of the demo scene (19 meshes under a root turned by -90 degrees about x: rows with
+    one entry each up to 4e-8): every (instance, triangle) pair once, leaf records and boxes checked
+    independently of the builder."""
+    rc, counts, why, err = check_flat(casa, True)
+    assert rc == 0, err
+    assert why == ""
+    assert counts[0] == len(casa.triangles) == 34689
+    assert len(casa.triangles) / 6 <= counts[1] <= len(casa.triangles)
+    assert counts[2] >= counts[0] / 2 and counts[3] == 0
+
+
+def test_flat_tree_of_rotated_mirrored_and_repeated_instances():
+    """Instances rotated off the axes, scaled unevenly, mirrored, several on one mesh, a one- and a two-triangle
+    mesh: the default mode refuses (and says why), the forced mode builds a tree that passes the same checks."""
+    rng = np.random.default_rng(9)
+    sb = scene.SceneBuilder()
+    ids = [sb.add_mesh(_random_mesh(rng, n)) for n in (300, 1, 2, 150)]
+    sb.add_instance(ids[0])
+    sb.add_instance(ids[0], scene.transform_matrix((0.5, 0.2, -0.3), (30, 45, 60), (1.0, 0.2, 3.0)))
+    sb.add_instance(ids[0], scene.transform_matrix((-0.5, 0, 0), (0, 0, 0), (-1.0, 1.0, 1.0)))
+    sb.add_instance(ids[1], scene.transform_matrix((2, 0, 0), (0, 90, 0), (1, 1, 1)))
+    sb.add_instance(ids[2], scene.transform_matrix((0, 2, 0), (10, 20, 30), (2, 2, 2)))
+    sb.add_instance(ids[3], scene.transform_matrix((0, 0, 3), (180, 0, 90), (1, 1, 1)))
+    sd = sb.finish()
+    rc, counts, why, err = check_flat(sd, True)
+    assert rc == 0 and counts[0] == 0 and "rotated off the axes" in why
+    rc, counts, why, err = check_flat(sd, False)
+    assert rc == 0, err
+    assert why == "" and counts[0] == 3 * 300 + 1 + 2 + 150
+
+
+def test_flat_tree_refusals():
+    """Singular and badly conditioned instance matrices, boxes that are not finite: no flat tree, no error."""
+    rng = np.random.default_rng(10)
+    for scale, word in (((1.0, 0.0, 1.0), None), ((1.0, 1e-4, 1.0), "conditioned")):
+        sb = scene.SceneBuilder()
+        m = sb.add_mesh(_random_mesh(rng, 50))
+        sb.add_instance(m)
+        sb.add_instance(m, scene.transform_matrix((1, 0, 0), (0, 0, 0), scale))
+        sd = sb.finish()
+        inst = sd.instances.copy()
+        if word is None:
+            inst["w2l"][1][:] = 0.0   # (whatever the inverse of a singular matrix came out as: make it singular for sure)
+            inst["w2l"][1][15] = 1.0
+            word = "singular"
+        else:
+            # rows of very different length AND a shear: | A | | W | is large
+            w = inst["w2l"][1].reshape(4, 4).copy()
+            w[1, 0] = 1e4 * w[0, 0]
+            inst["w2l"][1] = w.reshape(16)
+        rc, counts, why, err = check_flat(sd, False, instances=inst)
+        assert rc == 0, err
+        assert counts[0] == 0 and word in why, why
