@@ -17,6 +17,7 @@
 #include "path_state_io.h"
 #include "shade_vertex.h"
 #include "trace_fast.h"
+#include "trace_flat.h"
 
 namespace rta {
 namespace {
@@ -108,7 +109,8 @@ __device__ __forceinline__ void wave_sync() {
 #else
 #define RT_TAIL_OCC
 #endif
-template <bool QUANT>
+// MODE: 0 WNodes, 1 QNodes, 2 the flattened tree (as in trace_kernels.hip)
+template <int MODE>
 __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastScene fsc, TraceScene tsc, DrawParams dp, int dep0,
                                                                const unsigned *queue_in, const unsigned *count_in,
                                                                unsigned *next_batch) {
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastS
             {
                 TailSource src{wp, dp.rays, dp.shadow};
                 TailSink sink{wp, dp.hits, dp.shadow, dp.thr, dp.acc};
-                trace_ordered<QUANT, LocalRayFeed>(fsc, src, sink, nullptr, 2u * TAIL_PPW, s_stack);
+                if constexpr(MODE == 2) trace_flat<LocalRayFeed>(fsc, src, sink, nullptr, 2u * TAIL_PPW, s_stack);
+                else trace_ordered<MODE == 1, LocalRayFeed>(fsc, src, sink, nullptr, 2u * TAIL_PPW, s_stack);
             }
             wave_sync();
             const unsigned long long m_a = __ballot(lane < TAIL_PPW && (wp[lane < TAIL_PPW ? lane : 0u] & TP_AMBIGUOUS) != 0u);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastS
 
 void launch_path_tail(hipStream_t s, const FastScene &fsc, const TraceScene &tsc, const DrawParams &dp, int dep0, int blocks,
                       const unsigned *queue_in, const unsigned *count_in, unsigned *next_batch) {
-    hipLaunchKernelGGL(fsc.hdr.quantised ? path_tail_kernel<true> : path_tail_kernel<false>, dim3(blocks), dim3(TAIL_BLOCK), 0, s, fsc, tsc,
+    hipLaunchKernelGGL(fsc.flat_buf ? path_tail_kernel<2> : (fsc.hdr.quantised ? path_tail_kernel<1> : path_tail_kernel<0>), dim3(blocks), dim3(TAIL_BLOCK), 0, s, fsc, tsc,
                        dp, dep0, queue_in, count_in, next_batch);
 }
 

@@ -27,6 +27,16 @@
 // at no cost per node: near planes are met from the origin moved by pad along the ray's
 // direction signs, far planes from the origin moved the other way.  The host builds no flat
 // tree when an instance's matrix is singular or cond exceeds 256.
+//
+// The same padding pays for cheaper box arithmetic.  A ray never changes space while it walks, so
+// the slab distance (p - o) / d of a grid plane p = origin + step * scale is evaluated as
+//     step * (scale / d) + (origin / d - o / d)
+// with o / d made once per ray and the two node terms once per node and axis: a conversion and
+// one multiply-add per plane instead of a conversion, the decode, a subtraction and a product.
+// Its rounding moves a plane by at most 3 u (|o| + reach) -- inside pad.  All of it stays finite:
+// |1/d| is capped at 2^80, the host refuses coordinates beyond 1e12, and a ray whose largest
+// direction component lies outside [2^-40, 2^40] or whose origin lies beyond 2^40 is walked
+// without culling (the triangle tests decide, as ever).
 #pragma once
 #include "trace_fast.h"
 
@@ -50,7 +60,7 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
     int sp = 0;
     float wox = 0, woy = 0, woz = 0, wdx = 0, wdy = 0, wdz = 0;  // world ray
     float wix = 0, wiy = 0, wiz = 0;                             // 1 / direction
-    float onx = 0, ony = 0, onz = 0, ofx = 0, ofy = 0, ofz = 0;  // origin as near / far planes see it (padding)
+    float cnx = 0, cny = 0, cnz = 0, cfx = 0, cfy = 0, cfz = 0;  // -(origin as near / far planes see it) / direction
     LaneHit best;
     best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
     float second_t = RT_INF, abs_slack = 0.0f;
@@ -69,21 +79,35 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                     any_hit = ah;
                     wox = o[0]; woy = o[1]; woz = o[2];
                     wdx = d[0]; wdy = d[1]; wdz = d[2];
-                    wix = fast_rcp(wdx); wiy = fast_rcp(wdy); wiz = fast_rcp(wdz);
                     const float o1 = fabsf(wox) + fabsf(woy) + fabsf(woz);
+                    const float dm = fmaxf(fabsf(wdx), fmaxf(fabsf(wdy), fabsf(wdz)));
+                    // The slab distance of a plane p is (p - o) / d = p * (1/d) - o * (1/d): with the ray fixed for
+                    // its whole walk, the second product is made once here and a plane costs one multiply-add.
+                    // 1/d is kept finite (|1/d| <= 2^80; a component below 2^-80 of a direction whose largest one
+                    // is at least 2^-40 can only matter at distances no hit has), so that no product is inf - inf.
+                    wix = fminf(fmaxf(fast_rcp(wdx), -0x1p80f), 0x1p80f);
+                    wiy = fminf(fmaxf(fast_rcp(wdy), -0x1p80f), 0x1p80f);
+                    wiz = fminf(fmaxf(fast_rcp(wdz), -0x1p80f), 0x1p80f);
                     const float pad = sc.flat_pad * (o1 + sc.flat_reach);
-                    onx = wox + copysignf(pad, wdx); ofx = wox - copysignf(pad, wdx);
-                    ony = woy + copysignf(pad, wdy); ofy = woy - copysignf(pad, wdy);
-                    onz = woz + copysignf(pad, wdz); ofz = woz - copysignf(pad, wdz);
+                    cnx = -((wox + copysignf(pad, wdx)) * wix); cfx = -((wox - copysignf(pad, wdx)) * wix);
+                    cny = -((woy + copysignf(pad, wdy)) * wiy); cfy = -((woy - copysignf(pad, wdy)) * wiy);
+                    cnz = -((woz + copysignf(pad, wdz)) * wiz); cfz = -((woz - copysignf(pad, wdz)) * wiz);
+                    if(!(dm >= 0x1p-40f && dm <= 0x1p40f && o1 <= 0x1p40f)) {
+                        // a ray far outside the numbers above: no culling at all (every box passes), the
+                        // triangle tests decide as ever
+                        wix = wiy = wiz = 0.0f;
+                        cnx = cny = cnz = -1.0f;
+                        cfx = cfy = cfz = 3e38f;
+                    }
                     best.t = RT_INF; best.u = 0; best.v = 0; best.tri = -1; best.inst = -1;
                     second_t = RT_INF;
                     abs_slack = 1e-6f * (o1 + sc.hdr.extent);
                     active = true;
                     sp = 0;
                     tn = 0.0f;
-                    // a NaN component: a certain miss (trace_core.h); an infinite origin: every triangle
-                    // test of the reference computes NaN distances and fails
-                    have = !ray_has_nan(o, d) && o1 < 3e38f;
+                    // a NaN component: a certain miss (trace_core.h); an infinite origin or a zero direction:
+                    // every triangle test of the reference computes NaN coordinates and fails
+                    have = !ray_has_nan(o, d) && o1 < 3e38f && dm > 0.0f;
                     ref = sc.flat_root_ref;
                 }
             }
@@ -162,10 +186,14 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                 const unsigned nx = ngx ? hx : lx, fx = ngx ? lx : hx;
                 const unsigned ny = ngy ? hy : ly, fy = ngy ? ly : hy;
                 const unsigned nz = ngz ? hz : lz, fz = ngz ? lz : hz;
-#define RT_Q(packed, i, scale, org, o, inv) ((__builtin_fmaf((float)(((packed) >> (8 * (i))) & 0xFFu), scale, org) - (o)) * (inv))
-#define RT_QBOX(i, T_IN, T_OUT)                                                                                              \
-    T_IN = fmaxf(0.0f, fmaxf(fmaxf(RT_Q(nx, i, sx, q0.x, onx, wix), RT_Q(ny, i, sy, q0.y, ony, wiy)), RT_Q(nz, i, sz, q0.z, onz, wiz))); \
-    T_OUT = fminf(RT_INF, fminf(fminf(RT_Q(fx, i, sx, q0.x, ofx, wix), RT_Q(fy, i, sy, q0.y, ofy, wiy)), RT_Q(fz, i, sz, q0.z, ofz, wiz)))
+                // per node and axis: distance per grid step, and the distances of the grid's origin
+                const float ax = sx * wix, ay = sy * wiy, az = sz * wiz;
+                const float bnx = __builtin_fmaf(q0.x, wix, cnx), bny = __builtin_fmaf(q0.y, wiy, cny), bnz = __builtin_fmaf(q0.z, wiz, cnz);
+                const float bfx = __builtin_fmaf(q0.x, wix, cfx), bfy = __builtin_fmaf(q0.y, wiy, cfy), bfz = __builtin_fmaf(q0.z, wiz, cfz);
+#define RT_Q(packed, i, a, b) __builtin_fmaf((float)(((packed) >> (8 * (i))) & 0xFFu), a, b)
+#define RT_QBOX(i, T_IN, T_OUT)                                                                                  \
+    T_IN = fmaxf(0.0f, fmaxf(fmaxf(RT_Q(nx, i, ax, bnx), RT_Q(ny, i, ay, bny)), RT_Q(nz, i, az, bnz)));          \
+    T_OUT = fminf(RT_INF, fminf(fminf(RT_Q(fx, i, ax, bfx), RT_Q(fy, i, ay, bfy)), RT_Q(fz, i, az, bfz)))
                 RT_QBOX(0, t0, x0);
                 RT_QBOX(1, t1, x1);
                 RT_QBOX(2, t2, x2);

@@ -882,12 +882,12 @@ bool build_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const Triang
                 }
             }
             for(int k = 0; k < 3; k++)
-                if(!std::isfinite(b.mi[k]) || !std::isfinite(b.mx[k]) || std::fabs(b.mi[k]) > 1e17f || std::fabs(b.mx[k]) > 1e17f) { bad[i] = 1; return; }
+                if(!std::isfinite(b.mi[k]) || !std::isfinite(b.mx[k]) || std::fabs(b.mi[k]) > 1e12f || std::fabs(b.mx[k]) > 1e12f) { bad[i] = 1; return; }
         }
     });
     for(size_t i = 0; i < n_inst; i++)
         if(bad[i]) {
-            why_not = "instance " + std::to_string(i) + ": a box is not finite";
+            why_not = "instance " + std::to_string(i) + ": a box is not finite or lies beyond 1e12";
             return false;
         }
     // ---- one SAH tree over them, then four-wide
