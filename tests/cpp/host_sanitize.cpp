@@ -65,6 +65,35 @@ int main(int argc, char **argv) {
     for(int fmt = -1; fmt <= 1; fmt++)
         EXPECT(pt_host_check_traversal_layout(mesh_nodes.data(), n_nodes, tris.data(), n_tris, scene_nodes.data(), 2 * n_inst - 1,
                                               inst.data(), n_inst, fmt, counts) == PT_OK);
+    // the flattened tree of the same scene (rotated, mirrored, 1e-3-scaled instances; a one-triangle mesh):
+    // refused by the default gate, built and checked when forced
+    {
+        char why[128];
+        EXPECT(pt_host_check_flat_layout(mesh_nodes.data(), n_nodes, tris.data(), n_tris, scene_nodes.data(), 2 * n_inst - 1, inst.data(),
+                                         n_inst, 1, counts, why, sizeof why) == PT_OK && counts[0] == 0 && why[0] != 0);
+        EXPECT(pt_host_check_flat_layout(mesh_nodes.data(), n_nodes, tris.data(), n_tris, scene_nodes.data(), 2 * n_inst - 1, inst.data(),
+                                         n_inst, 0, counts, why, 4) == PT_OK);
+        EXPECT(counts[0] > 0 || why[0] != 0);
+        // without the 1e-3 scale (whose matrix is too badly conditioned): built for sure, on several threads
+        std::vector<float> l2w_b = l2w;
+        {
+            float pos[3] = {1, 2, 3}, rot[3] = {10, 20, 30}, scl[3] = {1.5f, 1.0f, 2.0f};
+            EXPECT(pt_host_transform_matrix(pos, rot, scl, &l2w_b[8 * 16]) == PT_OK);
+        }
+        std::vector<uint8_t> inst_b(n_inst * 112), scene_b((2 * n_inst - 1) * 48);
+        EXPECT(pt_host_build_scene(root_box.data(), siz.data(), depth.data(), n_mesh, l2w_b.data(), mesh_index.data(), material_ptr.data(),
+                                   n_inst, inst_b.data(), scene_b.data(), stats) == PT_OK);
+        EXPECT(pt_host_check_flat_layout(mesh_nodes.data(), n_nodes, tris.data(), n_tris, scene_b.data(), 2 * n_inst - 1, inst_b.data(),
+                                         n_inst, 0, counts, why, sizeof why) == PT_OK);
+        EXPECT(counts[0] == 1 + 2 + 3 + 257 + 5000 + 64 + 1 + 2 + 3);
+        // (an instance rooted inside a tree and one rooted at a leaf: the flat tree takes any root)
+        std::vector<uint8_t> inst3 = inst_b;
+        *reinterpret_cast<int32_t *>(&inst3[0 * 112 + 68]) = n_mesh + 3;
+        *reinterpret_cast<int32_t *>(&inst3[1 * 112 + 68]) = (int32_t)n_nodes - 1;
+        EXPECT(pt_host_check_flat_layout(mesh_nodes.data(), n_nodes, tris.data(), n_tris, scene_b.data(), 2 * n_inst - 1, inst3.data(),
+                                         n_inst, 0, counts, nullptr, 0) == PT_OK);
+        EXPECT(counts[0] > 5000);
+    }
     // an instance rooted inside a tree, one rooted at a leaf; then indices out of range
     {
         std::vector<uint8_t> inst2 = inst;
