@@ -599,7 +599,7 @@ int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow) {
         if(!rc) rc = l.queue_a.ensure(npix * 4);
         if(!rc) rc = l.queue_b.ensure(npix * 4);
         if(!rc) rc = l.queue_s.ensure(npix * 4);
-        if(!rc) rc = l.queue_r.ensure(npix * 4);
+        if(!rc) rc = l.queue_r.ensure(2 * npix * 4);  // undecided extend rays and given-up occlusion queries of one vertex
         if(!rc) rc = l.counters.ensure(CNT_TOTAL * 4);
         if(rc) return rc;
     }
@@ -1178,16 +1178,14 @@ int pt_pass_draw(pt_pass *p) {
                 launch_path_trace_fast(s, fsc, grid, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, dp.rays,
                                        dp.hits, dp.shadow, (int)npix, cnt + CNT_NEXT + 2 * dep + 1, qr, cnt + CNT_REDO + dep + 1, dp.thr,
                                        dp.acc, dp.stats + 2);
-                launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep + 1, dp.rays, dp.hits, cnt + CNT_NEXT_REDO + dep + 1, true);
+                launch_path_redo(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep + 1, dp.rays, dp.hits, dp.shadow, dp.thr, dp.acc,
+                                 cnt + CNT_NEXT_REDO + dep + 1);
             } else {
                 {
+                    // (analytic lights, or the reference's order asked for: occlusion queries in the reference's order)
                     ScopedTimer t(p, K_SHADOW);
-                    if(ordered && n_shadow == 1)
-                        launch_shadow_fast(s, fsc, grid, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, (int)npix,
-                                           cnt + CNT_NEXT + 2 * dep + 1);
-                    else
-                        launch_shadow(s, sc, grid, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
-                                      cnt + CNT_NEXT + 2 * dep + 1);
+                    launch_shadow(s, sc, grid, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
+                                  cnt + CNT_NEXT + 2 * dep + 1);
                 }
                 extend(dep + 1, q_out);
             }

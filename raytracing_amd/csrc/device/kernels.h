@@ -90,9 +90,11 @@ void launch_extend_fast(hipStream_t s, const FastScene &sc, int blocks, const un
 // shadow stage: ray (q, k) for q < *count, k < n_shadow; marks visible entries
 void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                    const PathRay *rays, ShadowEntry *shadow, int n_shadow, int npix, unsigned *next_counter);
-// sky-only (n_shadow == 1) ordered form
-void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
-                        const PathRay *rays, ShadowEntry *shadow, int npix, unsigned *next_counter);
+// reference-order pass over what launch_path_trace_fast left undecided: extend rays (entries are path slots) and,
+// tagged with bit 31, sky occlusion queries, whose light sample is applied where the query ends
+void launch_path_redo(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                      const PathRay *rays, PathHit *hits, const ShadowEntry *shadow, const PathThroughput *thr, PathAccum *acc,
+                      unsigned *next_counter);
 
 void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue_e, const unsigned *count_e,
                             const unsigned *queue_s, const unsigned *count_s, const PathRay *rays, PathHit *hits,

@@ -31,7 +31,8 @@ constexpr int TAIL_BLOCK = 256;
 static_assert(TAIL_BLOCK == FAST_BLOCK && TAIL_BLOCK == TRACE_BLOCK, "the traversal stacks are laid out for 256 threads");
 
 // one word per carried path, in LDS: slot number and what shade left for it
-constexpr unsigned TP_SLOT = (1u << 29) - 1u;
+constexpr unsigned TP_SLOT = (1u << 28) - 1u;
+constexpr unsigned TP_AMBIGUOUS_S = 1u << 28;  // its occlusion query was given up by the ordered traversal (trace_fast.h, rule (5))
 constexpr unsigned TP_AMBIGUOUS = 1u << 29;  // its extend ray must be traced again in the reference's order
 constexpr unsigned TP_CONTINUES = 1u << 30;  // an extend ray is due
 constexpr unsigned TP_SHADOW = 1u << 31;     // a sky light sample waits for its occlusion ray
@@ -71,30 +72,51 @@ struct TailSink {
         if(idx < TAIL_PPW) {
             const unsigned w = wp[idx];
             write_path_hit(hits, w & TP_SLOT, h);  // (provisional for an ambiguous ray: bounds its second pass)
-            if(ambiguous) wp[idx] = w | TP_AMBIGUOUS;
+            if(ambiguous) atomicOr(&wp[idx], TP_AMBIGUOUS);  // (the path's occlusion query may flag the same word from another lane)
+        } else if(ambiguous) {
+            atomicOr(&wp[idx - TAIL_PPW], TP_AMBIGUOUS_S);
         } else {
             apply_sky_sample(shadow, thr, acc, wp[idx - TAIL_PPW] & TP_SLOT, h);
         }
     }
 };
-// second pass over the wave's undecided extend rays, in the reference's order
+// second pass over the wave's undecided rays, in the reference's order: idx < PPW the extend ray of path idx,
+// else the occlusion query of path idx - PPW
 struct TailRedoSource {
     const unsigned *wp;
     const PathRay *rays;
     const PathHit *hits;
-    __device__ float bound(unsigned idx) const { return hits[wp[idx] & TP_SLOT].t; }
+    const ShadowEntry *shadow;
+    __device__ float bound(unsigned idx) const { return idx < TAIL_PPW ? hits[wp[idx] & TP_SLOT].t : RT_INF; }
     __device__ bool load(unsigned idx, float o[3], float d[3], bool &any_hit) const {
-        const unsigned w = wp[idx];
-        if(!(w & TP_AMBIGUOUS)) return false;
-        load_path_ray(rays, w & TP_SLOT, o, d);
-        any_hit = false;
+        const bool ext = idx < TAIL_PPW;
+        const unsigned w = wp[ext ? idx : idx - TAIL_PPW], px = w & TP_SLOT;
+        if(ext) {
+            if(!(w & TP_AMBIGUOUS)) return false;
+            load_path_ray(rays, px, o, d);
+            any_hit = false;
+            return true;
+        }
+        if(!(w & TP_AMBIGUOUS_S)) return false;
+        const float4 *e = reinterpret_cast<const float4 *>(shadow + px);
+        const float4 a = e[0];
+        const float4 ro = *reinterpret_cast<const float4 *>(rays + px);
+        o[0] = ro.x; o[1] = ro.y; o[2] = ro.z;
+        d[0] = a.x; d[1] = a.y; d[2] = a.z;
+        any_hit = true;
         return true;
     }
 };
 struct TailRedoSink {
     const unsigned *wp;
     PathHit *hits;
-    __device__ void store(unsigned idx, const LaneHit &h) const { write_path_hit(hits, wp[idx] & TP_SLOT, h); }
+    const ShadowEntry *shadow;
+    const PathThroughput *thr;
+    PathAccum *acc;
+    __device__ void store(unsigned idx, const LaneHit &h) const {
+        if(idx < TAIL_PPW) write_path_hit(hits, wp[idx] & TP_SLOT, h);
+        else apply_sky_sample(shadow, thr, acc, wp[idx - TAIL_PPW] & TP_SLOT, h);
+    }
 };
 
 // what one lane stores must be seen by whichever lane of the wave reads it next
@@ -154,12 +176,13 @@ __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastS
                 else trace_ordered<MODE == 1, LocalRayFeed>(fsc, src, sink, nullptr, 2u * TAIL_PPW, s_stack);
             }
             wave_sync();
-            const unsigned long long m_a = __ballot(lane < TAIL_PPW && (wp[lane < TAIL_PPW ? lane : 0u] & TP_AMBIGUOUS) != 0u);
-            if(m_a != 0ull) {
-                n_redo += (unsigned)__popcll(m_a);
-                TailRedoSource src{wp, dp.rays, dp.hits};
-                TailRedoSink sink{wp, dp.hits};
-                trace_persistent<LocalRayFeed>(tsc, src, sink, nullptr, TAIL_PPW, s_stack);
+            const unsigned flags = lane < TAIL_PPW ? wp[lane] : 0u;
+            const unsigned long long m_a = __ballot((flags & TP_AMBIGUOUS) != 0u), m_as = __ballot((flags & TP_AMBIGUOUS_S) != 0u);
+            if((m_a | m_as) != 0ull) {
+                n_redo += (unsigned)(__popcll(m_a) + __popcll(m_as));
+                TailRedoSource src{wp, dp.rays, dp.hits, dp.shadow};
+                TailRedoSink sink{wp, dp.hits, dp.shadow, dp.thr, dp.acc};
+                trace_persistent<LocalRayFeed>(tsc, src, sink, nullptr, 2u * TAIL_PPW, s_stack);
                 wave_sync();
             }
         }

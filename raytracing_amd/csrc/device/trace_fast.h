@@ -27,6 +27,13 @@
 //       box (the only results that could have pruned the winner away) is reported as
 //       ambiguous: the caller re-traces it with the reference-order kernel (trace_core.h),
 //       which is exact by construction.
+//   (5) every direction component the ray is traced with -- in world space and in the space of
+//       each instance it enters -- is a NORMAL number.  With a zero component the reference's
+//       slab test divides 0 by 0 where the origin lies on a box plane, and its NaN-dropping
+//       min / max then pass a box of no thickness whose ancestors FAIL (a child passing no longer
+//       implies its parents do); with a denormal component the hardware reciprocal is infinite
+//       where the quotient is not.  Such a ray is reported as ambiguous at once -- closest-hit
+//       and occlusion queries alike -- and left to the reference-order kernel.
 // The triangle test itself is the reference's Moller-Trumbore, bit for bit.
 // Occlusion queries ("is there any candidate hit") have no order dependence at all.
 // (The host refuses this kernel for buffers whose child boxes are not inside their parents'.)
@@ -73,6 +80,10 @@ struct FastScene {
 // product that is at most 2.5 ulp = 3e-7 away from the reference's IEEE quotient, a third of
 // the 1e-6 the comparisons are relaxed by.
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// some component is zero or denormal (rule (5) above; NaN components are the caller's business)
+__device__ __forceinline__ bool has_subnormal_component(float x, float y, float z) {
+    return fminf(fabsf(x), fminf(fabsf(y), fabsf(z))) < 1.17549435e-38f;
+}
 
 // Slab distances with a reciprocal direction: entry (>= 0) and exit.
 __device__ __forceinline__ void slab_range(float lox, float loy, float loz, float hix, float hiy, float hiz, float ox,
@@ -127,6 +138,7 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
 
     bool active = false, have = false, exhausted = false, any_hit = false;
+    bool uncertain = false;  // rule (5): this ray is the reference-order kernel's
     Feed feed(n_rays);
     unsigned ray_idx = 0;
     int sp = 0;
@@ -176,7 +188,13 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                                          sc.hdr.root_hi[1], sc.hdr.root_hi[2], wox, woy, woz, wdx, wdy, wdz, t0);
                         tn = t0;
                     }
-                    if(ray_has_nan(o, d)) have = false;  // a certain miss, see trace_core.h
+                    uncertain = false;
+                    if(ray_has_nan(o, d)) {
+                        have = false;  // a certain miss, see trace_core.h
+                    } else if(has_subnormal_component(wdx, wdy, wdz)) {
+                        uncertain = true;
+                        have = false;
+                    }
                     ref = sc.hdr.wide_root_ref;
                 }
             }
@@ -209,8 +227,11 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                     // itself means box and triangle arithmetic disagree: nothing is assumed then,
                     // and the second pass starts without a bound.
                     const bool odd = best_gate > best.t * 1.0005f + 4.0f * abs_slack;
-                    const bool ambiguous = !any_hit && best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f);
+                    const bool ambiguous = uncertain || (!any_hit && best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f));
                     if(ambiguous && odd) best.t = RT_INF;
+                    if(uncertain) {  // nothing found so far counts: the second pass starts without a bound
+                        best.t = RT_INF; best.tri = -1; best.inst = -1;
+                    }
                     sink.store(ray_idx, best, ambiguous);
                     active = false;
                 }
@@ -373,6 +394,11 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                     inst_tw = tw;
                     cur_inst = (int)((idx - sc.hdr.inst_base) >> 1);
                     ref = __float_as_uint(q3.z);  // wide mesh root; its own box is implied by the boxes below it
+                    if(has_subnormal_component(cdx, cdy, cdz)) {  // rule (5): give the whole ray up
+                        uncertain = true;
+                        have = false;
+                        sp = 0;
+                    }
                 }
             } else if(serve_leaf && is_leaf) {
                 // triangle leaf: q0, q1.xy parent box; then v0, e1, e2.  The first leaf of a pair hands

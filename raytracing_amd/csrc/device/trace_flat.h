@@ -55,6 +55,7 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
 
     bool active = false, have = false, exhausted = false, any_hit = false;
+    bool uncertain = false;  // rule (5) of trace_fast.h: this ray is the reference-order kernel's
     Feed feed(n_rays);
     unsigned ray_idx = 0;
     int sp = 0;
@@ -108,6 +109,11 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                     // a NaN component: a certain miss (trace_core.h); an infinite origin or a zero direction:
                     // every triangle test of the reference computes NaN coordinates and fails
                     have = !ray_has_nan(o, d) && o1 < 3e38f && dm > 0.0f;
+                    uncertain = false;
+                    if(have && has_subnormal_component(wdx, wdy, wdz)) {
+                        uncertain = true;
+                        have = false;
+                    }
                     ref = sc.flat_root_ref;
                 }
             }
@@ -132,8 +138,11 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                 } else {
                     // (the same decision as at the end of a ray in trace_ordered)
                     const bool odd = best_gate > best.t * 1.0005f + 4.0f * abs_slack;
-                    const bool ambiguous = !any_hit && best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f);
+                    const bool ambiguous = uncertain || (!any_hit && best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f));
                     if(ambiguous && odd) best.t = RT_INF;
+                    if(uncertain) {
+                        best.t = RT_INF; best.tri = -1; best.inst = -1;
+                    }
                     sink.store(ray_idx, best, ambiguous);
                     active = false;
                 }
@@ -237,6 +246,11 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                 const float ldx = (q4.x * wdx + q4.y * wdy) + q4.z * wdz;
                 const float ldy = (q5.x * wdx + q5.y * wdy) + q5.z * wdz;
                 const float ldz = (q6.x * wdx + q6.y * wdy) + q6.z * wdz;
+                if(has_subnormal_component(ldx, ldy, ldz)) {  // rule (5): give the whole ray up
+                    uncertain = true;
+                    have = false;
+                    sp = 0;
+                }
                 const float v0x = q1.z, v0y = q1.w, v0z = q2.x, e1x = q2.y, e1y = q2.z, e1z = q2.w, e2x = q3.x, e2y = q3.y, e2z = q3.z;
                 // intersect_triangle, shader/pathtracing.glsl:224-249
                 const float sx = lox - v0x, sy = loy - v0y, sz = loz - v0z;
@@ -246,7 +260,7 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                 const float t = (s2x * e2x + s2y * e2y + s2z * e2z) * k;
                 const float u = (s1x * sx + s1y * sy + s1z * sz) * k;
                 const float v = (s2x * ldx + s2y * ldy + s2z * ldz) * k;
-                if(RT_RAY_MINDIS <= t && 0.0f <= u && 0.0f <= v && u + v <= 1.0f) {
+                if(!uncertain && RT_RAY_MINDIS <= t && 0.0f <= u && 0.0f <= v && u + v <= 1.0f) {
                     if(t < best.t) {
                         // a candidate only if the reference would have reached this leaf: its parent's box in
                         // the instance's space and the instance's scene leaf box in world space, exactly

@@ -221,8 +221,6 @@ struct ShadowSink {
         const bool visible = h.tri < 0 || h.t * h.t > e->dis2;
         if(visible) e->flags |= 4u;
     }
-    // occlusion queries are never ambiguous
-    __device__ void store(unsigned idx, const LaneHit &h, bool) const { store(idx, h); }
 };
 
 __global__ __launch_bounds__(TRACE_BLOCK) void shadow_kernel(TraceScene sc, const unsigned *queue,
@@ -233,18 +231,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void shadow_kernel(TraceScene sc, cons
     ShadowSource src{queue, rays, shadow, n_shadow, npix};
     ShadowSink sink{queue, shadow, n_shadow, npix};
     trace_persistent(sc, src, sink, next_counter, *count * (unsigned)n_shadow, s_stack);
-}
-
-// sky-only form (n_shadow == 1): every query is an occlusion query
-template <int MODE>
-__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_fast_kernel(FastScene sc, const unsigned *queue,
-                                                                 const unsigned *count, const PathRay *rays,
-                                                                 ShadowEntry *shadow, int npix,
-                                                                 unsigned *next_counter) {
-    __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
-    ShadowSource src{queue, rays, shadow, 1, npix};
-    ShadowSink sink{queue, shadow, 1, npix};
-    trace_fast_any<MODE>(sc, src, sink, next_counter, *count, s_stack);
 }
 
 // ---- shadow rays of vertex d and extend rays of vertex d+1 in ONE launch ---------------------
@@ -273,15 +259,67 @@ struct ShadowApplySink {
         apply_sky_sample(shadow, thr, acc, queue[idx], h);
     }
 };
+// An occlusion query the ordered kernel gives up (a zero or denormal direction component, trace_fast.h) goes
+// on the same list as the undecided extend rays, tagged: the reference-order launch behind traces both kinds.
+constexpr unsigned REDO_SHADOW = 0x80000000u;
 struct PathSink {
     ExtendSinkFast e;
     ShadowApplySink s;
     unsigned n_extend;
     __device__ void store(unsigned idx, const LaneHit &h, bool ambiguous) const {
         if(idx < n_extend) e.store(idx, h, ambiguous);
+        else if(ambiguous) e.redo[atomicAdd(e.redo_count, 1u)] = s.queue[idx - n_extend] | REDO_SHADOW;
         else s.store(idx - n_extend, h);
     }
 };
+// the rays on that list
+struct RedoSource {
+    const unsigned *queue;
+    const PathRay *rays;
+    const PathHit *hits;  // what the ordered pass found for the extend rays: bounds their second pass
+    const ShadowEntry *shadow;
+    __device__ float bound(unsigned idx) const {
+        const unsigned w = queue[idx];
+        return (w & REDO_SHADOW) ? RT_INF : hits[w].t;
+    }
+    __device__ bool load(unsigned idx, float o[3], float d[3], bool &any_hit) const {
+        const unsigned w = queue[idx], px = w & ~REDO_SHADOW;
+        if(!(w & REDO_SHADOW)) {
+            load_path_ray(rays, px, o, d);
+            any_hit = false;
+            return true;
+        }
+        const float4 *e = reinterpret_cast<const float4 *>(shadow + px);  // (sample 0: the sky's)
+        const float4 a = e[0], b = e[1];
+        if(!(__float_as_uint(b.w) & 1u)) return false;
+        const float4 ro = *reinterpret_cast<const float4 *>(rays + px);
+        o[0] = ro.x; o[1] = ro.y; o[2] = ro.z;
+        d[0] = a.x; d[1] = a.y; d[2] = a.z;
+        any_hit = true;
+        return true;
+    }
+};
+struct RedoSink {
+    const unsigned *queue;
+    PathHit *hits;
+    const ShadowEntry *shadow;
+    const PathThroughput *thr;
+    PathAccum *acc;
+    __device__ void store(unsigned idx, const LaneHit &h) const {
+        const unsigned w = queue[idx];
+        if(w & REDO_SHADOW) apply_sky_sample(shadow, thr, acc, w & ~REDO_SHADOW, h);
+        else write_path_hit(hits, w, h);
+    }
+};
+
+__global__ __launch_bounds__(TRACE_BLOCK) void path_redo_kernel(TraceScene sc, const unsigned *queue, const unsigned *count,
+                                                                const PathRay *rays, PathHit *hits, const ShadowEntry *shadow,
+                                                                const PathThroughput *thr, PathAccum *acc, unsigned *next_counter) {
+    __shared__ uint2 s_stack[LDS_STACK * TRACE_BLOCK];
+    RedoSource src{queue, rays, hits, shadow};
+    RedoSink sink{queue, hits, shadow, thr, acc};
+    trace_persistent<SparseRayFeed>(sc, src, sink, next_counter, *count, s_stack);
+}
 
 template <int MODE>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel(
@@ -344,9 +382,10 @@ void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsign
                        n_shadow, npix, next_counter);
 }
 
-void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
-                        const PathRay *rays, ShadowEntry *shadow, int npix, unsigned *next_counter) {
-    hipLaunchKernelGGL(RT_PICK_FAST(shadow_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, shadow, npix,
+void launch_path_redo(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                      const PathRay *rays, PathHit *hits, const ShadowEntry *shadow, const PathThroughput *thr, PathAccum *acc,
+                      unsigned *next_counter) {
+    hipLaunchKernelGGL(path_redo_kernel, dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, queue, count, rays, hits, shadow, thr, acc,
                        next_counter);
 }
 

@@ -160,3 +160,74 @@ def test_moving_instances_drop_the_flat_tree(small_sky, oracle_mod, gpu_ctx):
     check(p.download(), ref)
     p.destroy()
     sb.release()
+
+
+def test_fuzzed_scenes_and_degenerate_rays_in_every_traversal_mode(oracle_mod, gpu_ctx):
+    """tools/flat_fuzz.py, a fixed prefix of it: random scenes (translations up to 1e4, scales 1e-3..1e3, mirrored,
+    axis-permuted and -- every third -- rotated instances, exactly flat grids) and rays from near and far with zero,
+    denormal and huge direction components, many of them lying IN the plane of a flat mesh.  With a zero component
+    the reference's slab test is 0/0 on a box plane and a box of no thickness passes while its ancestors fail; with a
+    denormal one the hardware reciprocal overflows where the quotient does not: the ordered kernels leave such rays
+    to the reference-order kernel.  All three modes against the oracle, bit for bit."""
+    import importlib.util
+    import os
+    from raytracing_amd import device
+    spec = importlib.util.spec_from_file_location("flat_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "flat_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(1)
+    given_up = 0
+    for k in range(12):
+        sd = fz.random_scene(rng, k % 3 == 2)
+        rays = fz.rays_for(sd, rng, 20000)
+        ref, _ = oracle_mod.OracleScene(sd).intersect(rays)
+        sb = device.SceneBuffers(gpu_ctx, sd)
+        for mode in (1, 2, 3):
+            p = device.PathTracingPass(gpu_ctx, 16, 16)
+            p.bind_scene(sb)
+            p.set_traversal(mode)
+            _check(device.trace_rays(p, rays), ref)
+            st = p.stats()
+            assert (st["flat_leaves"] > 0) == (mode == 3)
+            given_up += st["rays_retraced"] if mode == 3 else 0
+            p.destroy()
+        sb.release()
+    assert given_up > 10000   # (the axis-parallel rays)
+
+
+def test_sky_samples_with_a_zero_direction_component(casa, oracle_mod, gpu_ctx):
+    """A sky that is black but for one column at u = 0.5: every light sample points along
+    theta = (0.5 - 0.5) * 2 pi = 0, so its z component is sin(0) = 0 exactly (pathtracing.glsl:383-391), and every
+    occlusion query is one the ordered kernels give up: they go through the reference-order launch behind the
+    merged one, and through the tail launch's own second pass (a lone draw).  Outputs as the oracle's."""
+    from raytracing_amd import device, scene
+    w, h = 128, 72
+    rgb = np.zeros((32, 64, 3), np.float32)
+    rgb[4:20, 32] = (900.0, 800.0, 700.0)
+    sky = scene.Sky(rgb)
+    sb = device.SceneBuffers(gpu_ctx, casa, sky)
+    osc = oracle_mod.OracleScene(casa, sky)
+    jit = scene.mt19937_jitters(2)
+    prms = [scene.make_params(w, h, scene.casa_camera(), sky, spp=s, frame=1, jitter=jit[s - 1], max_depth=5) for s in (1, 2)]
+    ref, n_shadow, n_extend = None, 0, 0
+    for prm in prms:
+        ref, cnt = osc.render(prm, ref)
+        n_shadow += cnt["rays_shadow"]
+        n_extend += cnt["rays_extend"]
+    assert n_shadow > 2000 and float(np.asarray(ref["directLum"]).max()) > 0
+    for traversal, pipeline, tail in ((0, 3, -1), (3, 1, 1 << 30), (2, 1, 1 << 30), (3, 1, 0)):
+        p = device.PathTracingPass(gpu_ctx, w, h)
+        p.bind_scene(sb)
+        p.set_traversal(traversal)
+        p.set_pipeline(pipeline)
+        p.set_tail_threshold(tail)
+        for prm in prms:
+            p.set_params(prm)
+            p.draw()
+            gpu_ctx.synchronize()   # (a lone draw: the next one sees its queue lengths and may hand over to the tail launch)
+        check(p.download(), ref)
+        st = p.stats()
+        assert st["rays_shadow"] == n_shadow and st["rays_extend"] == n_extend, (traversal, pipeline, tail)
+        assert st["rays_retraced"] >= n_shadow * 0.9, (traversal, pipeline, tail)   # the occlusion queries, given up
+        p.destroy()
+    sb.release()
