@@ -231,3 +231,22 @@ def test_sky_samples_with_a_zero_direction_component(casa, oracle_mod, gpu_ctx):
         assert st["rays_retraced"] >= n_shadow * 0.9, (traversal, pipeline, tail)   # the occlusion queries, given up
         p.destroy()
     sb.release()
+
+
+def test_fuzzed_draws_in_every_mode(gpu_ctx):
+    """tools/render_fuzz.py, a fixed prefix: random small scenes with conductors, rough dielectrics, textures and 0-3
+    lights (some under a sky whose samples have a zero component), two accumulated draws at a random MAX_DEPTH, in
+    every traversal mode x {draws in flight, lone draws with the tail launch forced, lone draws without it}: all
+    seven outputs equal to the oracle's."""
+    import importlib.util
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    try:
+        spec = importlib.util.spec_from_file_location("render_fuzz", os.path.join(tools, "render_fuzz.py"))
+        rf = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(rf)
+        assert rf.run(16, 2, gpu_ctx, verbose=False) == 0
+    finally:
+        sys.path.remove(tools)

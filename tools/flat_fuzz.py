@@ -49,7 +49,10 @@ def random_scene(rng, rotated):
             sc = sc * 10.0 ** rng.uniform(-0.7, 0.7, 3)   # uneven
         if rng.random() < 0.3:
             sc[int(rng.integers(0, 3))] *= -1.0           # mirrored
-        b.add_instance(m, scene.transform_matrix(tuple(pos), tuple(rot), tuple(sc)))
+        mat = scene.transform_matrix(tuple(pos), tuple(rot), tuple(sc))
+        b.add_instance(m, mat)
+        if rng.random() < 0.25:
+            b.add_instance(m, mat)          # an exact duplicate: every hit ties with its twin in another instance
     return b.finish()
 
 
@@ -79,6 +82,19 @@ def rays_for(sd, rng, per_instance):
             d[sel] = dd + tiny
             origin[sel] = target[sel] - dd * ext[a] * 2.0
         rays.append(np.concatenate([origin, d], 1))
+        # rays through vertices and edge midpoints of the instance's triangles (shared by neighbours in a grid: ties)
+        mi = int(sd.mesh_index[k])
+        base = int(np.sum(sd.tri_count[:mi]))
+        tri = sd.triangles[base + rng.integers(0, int(sd.tri_count[mi]), per_instance // 4)]
+        ver = np.asarray(tri["ver"] if tri.dtype.names else tri[:, :9], np.float64).reshape(-1, 3, 3)
+        wgt = rng.choice([[1, 0, 0], [0, 1, 0], [0.5, 0.5, 0], [0, 0.5, 0.5], [1 / 3, 1 / 3, 1 / 3]], len(ver))
+        local = np.einsum("nk,nkc->nc", np.asarray(wgt, np.float64), ver)
+        m4 = np.asarray(sd.l2w[k], np.float64).reshape(4, 4)        # column major: m4[c][r]
+        world = local @ m4[:3, :3] + m4[3, :3]
+        org = world + rng.normal(0, 1, world.shape) * ext * 10.0 ** rng.uniform(-1, 2, (len(world), 1))
+        dd = world - org
+        dd /= np.maximum(np.linalg.norm(dd, axis=1, keepdims=True), 1e-300)
+        rays.append(np.concatenate([org, dd], 1))
     return np.ascontiguousarray(np.concatenate(rays), np.float32)
 
 
