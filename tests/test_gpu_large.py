@@ -41,6 +41,19 @@ def test_2m_triangles_dielectrics_textures_depth16_vs_oracle(gpu_ctx, small_sky,
     assert st["rays_extend"] + st["rays_shadow"] > 4 * w * h * spp              # several bounces per path on average (open scene)
     assert (got["instanceIndex"] >= 0).mean() > 0.5
     p.destroy()
+    # the same two draws over the flattened tree (2 M leaves: its layout is cut and built on several threads;
+    # rotated instances, so only on request)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    p.set_traversal(3)
+    for s in range(1, spp + 1):
+        p.set_params(scene.make_params(w, h, scene.synthetic_camera(), small_sky, spp=s, jitter=jit[s - 1], max_depth=depth))
+        p.draw()
+    got = p.download()
+    for k in ref:
+        assert _bit_equal(got[k], ref[k]), k
+    assert p.stats()["flat_leaves"] == len(sd.triangles)
+    p.destroy()
     sb.release()
 
 
@@ -102,17 +115,18 @@ def test_one_mesh_of_a_million_triangles_vs_oracle(gpu_ctx, small_sky, oracle_mo
     sb = device.SceneBuffers(gpu_ctx, sd, small_sky)
     prm = scene.make_params(w, h, scene.synthetic_camera(), small_sky, spp=1, max_depth=depth)
     images = []
-    for mode in (0, 1):
+    for mode in (0, 1, 3):          # (3: the flattened tree, a million leaves)
         p = device.PathTracingPass(gpu_ctx, w, h)
         p.bind_scene(sb)
         p.set_traversal(mode)
         p.set_params(prm)
         p.draw()
         images.append(p.download())
+        assert (p.stats()["flat_leaves"] > 1_000_000) == (mode == 3)
         p.destroy()
     ref, _ = oracle_mod.OracleScene(sd, small_sky).render(prm)
     for key in ref:
-        assert _bit_equal(images[0][key], ref[key]), key
-        assert _bit_equal(images[1][key], ref[key]), key
+        for im in images:
+            assert _bit_equal(im[key], ref[key]), key
     assert (images[0]["instanceIndex"] >= 0).mean() > 0.3
     sb.release()
