@@ -37,6 +37,10 @@ BODY(k_pkfma, DECL_P, asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[c]) : 
 BODY(k_pkmul, DECL_P, asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[c]) : "v"(k1)))
 BODY(k_pkadd, DECL_P, asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[c]) : "v"(k1)))
 BODY(k_cvtub, DECL_U, asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[c]) : "v"(u[c])))
+BODY(k_perm, DECL_U, asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a[c]) : "v"(u[c]), "v"(k1), "v"(k1)))
+BODY(k_bfe, DECL_U, asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(a[c]) : "v"(u[c])))
+BODY(k_andor, DECL_U, asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a[c]) : "v"(u[c]), "v"(k1), "v"(k1)))
+BODY(k_lshlor, DECL_U, asm volatile("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(a[c]) : "v"(u[c]), "v"(k1)))
 BODY(k_cvtu32, DECL_U, asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(a[c]) : "v"(u[c])))
 BODY(k_cndmask, DECL_U, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[c]) : "v"(k1)))
 BODY(k_minu, DECL_U, asm volatile("v_min_u32 %0, %0, %1" : "+v"(u[c]) : "v"(k1)))
@@ -78,6 +82,10 @@ int main() {
     run("v_pk_mul_f32", k_pkmul, 2);
     run("v_pk_add_f32", k_pkadd, 2);
     run("v_cvt_ubyte", k_cvtub, 1);
+    run("v_perm_b32", k_perm, 1);
+    run("v_bfe_u32", k_bfe, 1);
+    run("v_and_or_b32", k_andor, 1);
+    run("v_lshl_or_b32", k_lshlor, 1);
     run("v_cvt_u32", k_cvtu32, 1);
     run("v_cndmask", k_cndmask, 1);
     run("v_min_u32", k_minu, 1);
