@@ -14,19 +14,30 @@
 // candidate, (3) pruning beyond the near-tie band only, (4) the runner-up bookkeeping.  (2)-(4)
 // are kept as they are: a leaf record carries the exact parent box, the instance record the
 // exact scene leaf box, and both are tested with the reference's IEEE slab test before a closer
-// hit is accepted.  For (1) the tree's boxes must contain, in world space, every point at which
-// the reference could accept a hit on the leaf's triangle.  Such a point p_l = o_l + t d_l lies
-// in the parent box B (up to the rounding of the reference's own slab test), with
-// o_l = fl(W o), d_l = fl(W d) for the instance's world-to-local matrix W.  With A = W^-1:
+// hit is accepted.  For (1) the tree's boxes must be met by every ray for which the reference
+// could accept a hit on the leaf's triangle.  The reference accepts when the barycentrics it
+// computes for the local ray o_l = fl(W o), d_l = fl(W d) (W: the instance's world-to-local
+// matrix) lie in the unit simplex.  Their rounding error is g |o_l - v0| / (h sin a) for a ray
+// that meets the triangle's plane under the angle a (h: the triangle's height, g a few u), i.e.
+// the plane is crossed within g |o_l - v0| / sin a of the triangle -- and a ray that crosses a
+// plane under the angle a that close to a triangle passes the triangle itself within
+// g |o_l - v0| / cos a, however flat a is: the local ray misses the triangle by a few u of its
+// distance from the origin at most.  With A = W^-1:
 //     o + t d = A p_l - A (e_o + t e_d),   |e_o| + t |e_d| <= 4 u |W| (|o| + t |d|)
-// so the leaf's world box is the box of the eight corners of B under A (computed in double,
-// rounded outwards), and what remains is an ABSOLUTE error of at most 4 u cond (|o| + t|d|),
-// cond = || |A| |W| ||.  It is covered per ray: every box is widened by
+// so the leaf's world box is the box of the triangle's three vertices under A (computed in
+// double, rounded outwards; never larger than the box of the eight corners of the reference
+// parent box under A, which it is cut against), and what remains is an ABSOLUTE error of a few
+// u cond (|o| + t|d|), cond = || |A| |W| ||.  It is covered per ray: every box is widened by
 //     pad = flat_pad * (|o|_1 + flat_reach),   flat_pad = 64 u max cond over the instances,
 // flat_reach = the largest |coordinate| sum of the scene box (t |d| <= |o| + reach for any hit),
 // at no cost per node: near planes are met from the origin moved by pad along the ray's
 // direction signs, far planes from the origin moved the other way.  The host builds no flat
 // tree when an instance's matrix is singular or cond exceeds 256.
+// Pruning by entry distance assumes, as trace_fast.h does for the parent box, that the distance
+// the reference computes for a hit is not SMALLER than the ray's entry into the padded box of
+// what it hit by more than the near-tie band (0.1 % + 8e-6 (|o| + extent)); a hit found the other
+// way round (entry distance of the parent box beyond the hit) sends the ray to the
+// reference-order kernel.
 //
 // The same padding pays for cheaper box arithmetic.  A ray never changes space while it walks, so
 // the slab distance (p - o) / d of a grid plane p = origin + step * scale is evaluated as

@@ -852,7 +852,7 @@ bool build_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const Triang
     std::vector<const BVHNodeInfo *> scene_leaf(n_inst, nullptr);
     for(size_t k = 0; k < n_scene_nodes; k++)
         if(scene[k].instanceIndex >= 0 && (size_t)scene[k].instanceIndex < n_inst) scene_leaf[scene[k].instanceIndex] = &scene[k];
-    // ---- world boxes of the leaves: the eight corners of the reference parent box under A, rounded outwards
+    // ---- world boxes of the leaves: the eight corners of the reference parent box under A ...
     std::vector<Box> boxes(n);
     std::vector<uint8_t> bad(n_inst, 0);
     const unsigned threads = n_threads > 0 ? (unsigned)n_threads : layout_threads();
@@ -875,6 +875,26 @@ bool build_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const Triang
                         hi[r] = std::max(hi[r], v);
                     }
                 }
+                // ... cut down to the box of the triangle's own vertices under A: a hit the reference accepts lies on the
+                // triangle up to the rounding of its triangle test, which the per-ray padding of the traversal covers
+                // (trace_flat.h).  A triangle with a vertex that is not finite can never be hit and keeps the parent's box.
+                const float *tv = tris[mesh[lv[j].node].triangleIndex].ver;
+                bool finite = true;
+                for(int q = 0; q < 9; q++) finite = finite && std::isfinite(tv[q]);
+                if(finite) {
+                    double tlo[3] = {1e300, 1e300, 1e300}, thi[3] = {-1e300, -1e300, -1e300};
+                    for(int vtx = 0; vtx < 3; vtx++)
+                        for(int r = 0; r < 3; r++) {
+                            const double v = A.a[r][0] * tv[3 * vtx] + A.a[r][1] * tv[3 * vtx + 1] + A.a[r][2] * tv[3 * vtx + 2] + A.a[r][3];
+                            tlo[r] = std::min(tlo[r], v);
+                            thi[r] = std::max(thi[r], v);
+                        }
+                    for(int r = 0; r < 3; r++) {
+                        lo[r] = std::max(lo[r], tlo[r]);
+                        hi[r] = std::min(hi[r], thi[r]);
+                        if(lo[r] > hi[r]) lo[r] = hi[r] = 0.5 * (lo[r] + hi[r]);  // (they meet in a face, up to rounding)
+                    }
+                }
                 for(int k = 0; k < 3; k++) {
                     // (the double sums carry errors far below one float step: one more step outwards covers them)
                     b.mi[k] = std::nextafterf(std::nextafterf((float)lo[k], -INFINITY), -INFINITY);
@@ -892,9 +912,7 @@ bool build_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const Triang
         }
     // ---- one SAH tree over them, then four-wide
     SahTree tree;
-    // (built over the boxes the traversal will cull with: a leaf whose reference sibling is a subtree has a parent
-    // box several times its own size, and a tree shaped by the triangles' own boxes instead, then re-fitted,
-    // measured 12 % slower on the demo scene -- such leaves belong high in the tree)
+    // (built over the boxes the traversal will cull with)
     build_sah_tree(boxes.data(), (int)n, tree, (int)threads);
     std::vector<Box>().swap(boxes);
     const size_t n_nodes = tree.nodes.size();
@@ -1236,7 +1254,8 @@ bool verify_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const Trian
         err = "the flat tree holds " + std::to_string(n) + " leaves, the scene has " + std::to_string(want.size());
         return false;
     }
-    // world box of a leaf, from its own record: corners of the parent box through the inverse of its rows
+    // world box of a leaf, from its own record: corners of the parent box through the inverse of its rows, cut
+    // down to the box of the triangle's vertices through the same inverse
     auto leaf_box = [&](const FlatLeaf &l, float lo[3], float hi[3]) {
         long double w[3][4], a[3][3];
         for(int r = 0; r < 3; r++)
@@ -1258,6 +1277,22 @@ bool verify_accel_flat(const BVHNodeInfo *mesh, size_t n_mesh_nodes, const Trian
                 lo[r] = std::min(lo[r], (float)v);
                 hi[r] = std::max(hi[r], (float)v);
             }
+        }
+        const float *tv = tris[l.triangle].ver;
+        for(int q = 0; q < 9; q++)
+            if(!std::isfinite(tv[q])) return;
+        float tlo[3], thi[3];
+        for(int k = 0; k < 3; k++) { tlo[k] = std::numeric_limits<float>::infinity(); thi[k] = -tlo[k]; }
+        for(int vtx = 0; vtx < 3; vtx++)
+            for(int r = 0; r < 3; r++) {
+                const long double v = a[r][0] * (tv[3 * vtx] - w[0][3]) + a[r][1] * (tv[3 * vtx + 1] - w[1][3]) + a[r][2] * (tv[3 * vtx + 2] - w[2][3]);
+                tlo[r] = std::min(tlo[r], (float)v);
+                thi[r] = std::max(thi[r], (float)v);
+            }
+        for(int r = 0; r < 3; r++) {
+            lo[r] = std::max(lo[r], tlo[r]);
+            hi[r] = std::min(hi[r], thi[r]);
+            if(lo[r] > hi[r]) lo[r] = hi[r];  // (they meet in a face: a float step apart at most, either end lies in the built box)
         }
     };
     std::vector<uint8_t> seen(n_slots, 0);
