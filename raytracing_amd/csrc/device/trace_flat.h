@@ -275,12 +275,25 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                     if(t < best.t) {
                         // a candidate only if the reference would have reached this leaf: its parent's box in
                         // the instance's space and the instance's scene leaf box in world space, exactly
+                        // (as in trace_ordered: the relaxed test first, the twelve IEEE divisions of the exact
+                        // ones only when it neither fails nor passes with its margin to spare -- this code runs
+                        // for the one or two lanes of a leaf step that found a closer hit; fresh reciprocals,
+                        // since the per-ray ones are capped for the walk)
                         float te, tw = 0.0f;
-                        bool pass = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, lox, loy, loz, ldx, ldy, ldz, te);
+                        bool clear;
+                        bool pass = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, lox, loy, loz, fast_rcp(ldx), fast_rcp(ldy), fast_rcp(ldz), te, clear);
+                        if(pass && !clear) {
+                            float exact;
+                            pass = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, lox, loy, loz, ldx, ldy, ldz, exact);
+                        }
                         if(pass) {
                             const float4 *ip = reinterpret_cast<const float4 *>(sc.scene_buf + ((size_t)(sc.hdr.inst_base + 2u * inst) << 6));
                             const float4 b5 = ip[5], b6 = ip[6];
-                            pass = slab_test(b5.z, b5.w, b6.x, b6.y, b6.z, b6.w, wox, woy, woz, wdx, wdy, wdz, tw);
+                            pass = slab_fast(b5.z, b5.w, b6.x, b6.y, b6.z, b6.w, wox, woy, woz, fast_rcp(wdx), fast_rcp(wdy), fast_rcp(wdz), tw, clear);
+                            if(pass && !clear) {
+                                float exact;
+                                pass = slab_test(b5.z, b5.w, b6.x, b6.y, b6.z, b6.w, wox, woy, woz, wdx, wdy, wdz, exact);
+                            }
                         }
                         if(pass) {
                             second_t = fminf(second_t, best.t);
