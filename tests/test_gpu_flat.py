@@ -250,3 +250,61 @@ def test_fuzzed_draws_in_every_mode(gpu_ctx):
         assert rf.run(16, 2, gpu_ctx, verbose=False) == 0
     finally:
         sys.path.remove(tools)
+
+
+def test_grazing_rays_at_the_corners_of_triangle_boxes(oracle_mod, gpu_ctx):
+    """The flat tree culls with the box of a triangle's own vertices.  Rays that lie within 1e-1 .. 1e-7 rad of a
+    triangle's plane and are aimed at its vertices, edge midpoints and points just outside its edges enter that box
+    where they hit, which is where a distance computed by the reference's triangle test is least accurate; a second
+    sheet a hair below the first supplies the competing hits.  Flat and wavy sheets, on the axes and rotated off them,
+    near the origin and 3e3 away: all three traversal modes against the oracle."""
+    from raytracing_amd import device, scene
+    rng = np.random.default_rng(23)
+    b = scene.SceneBuilder()
+    u = np.linspace(-1, 1, 10)
+    gx, gz = np.meshgrid(u, u, indexing="ij")
+    flat = b.add_mesh(scene._grid_mesh(np.stack([gx, np.zeros_like(gx), gz], -1), 9, 9, 1.0))
+    wavy = b.add_mesh(scene._grid_mesh(np.stack([gx, 0.05 * np.sin(4 * gx) * np.cos(3 * gz), gz], -1), 9, 9, 1.0))
+    mats = []
+    for mesh, pos, rot, sc in ((flat, (0, 0, 0), (0, 0, 0), (1, 1, 1)), (flat, (0, -1e-4, 0), (0, 0, 0), (1, 1, 1)),
+                               (flat, (5, 1, 2), (20, 35, 50), (2, 2, 2)), (flat, (5, 1, 2), (20, 35, 50), (2.00001, 2, 2)),
+                               (wavy, (-4, 0, 1), (0, 90, 0), (1, 1, 1)), (wavy, (3e3, 2e3, -1e3), (10, 0, 80), (30, 30, 30)),
+                               (flat, (3e3, 2e3, -1e3), (10, 0, 80), (30, 30, 30))):
+        m = scene.transform_matrix(pos, rot, sc)
+        b.add_instance(mesh, m)
+        mats.append(np.asarray(m, np.float64).reshape(4, 4))
+    sd = b.finish()
+    rays = []
+    per = 6000
+    for k, m4 in enumerate(mats):   # column major: m4[c][r]
+        mi = int(sd.mesh_index[k])
+        base = int(np.sum(sd.tri_count[:mi]))
+        tri = sd.triangles[base + rng.integers(0, int(sd.tri_count[mi]), per)]
+        ver = np.asarray(tri["ver"] if tri.dtype.names else tri[:, :9], np.float64).reshape(-1, 3, 3)
+        wgt = np.asarray(rng.choice([[1, 0, 0], [0, 1, 0], [0, 0, 1], [0.5, 0.5, 0], [0, 0.5, 0.5], [0.5, 0, 0.5],
+                                     [1.001, -0.001, 0], [-0.001, 0.5, 0.501], [1 / 3, 1 / 3, 1 / 3]], per), np.float64)
+        target = np.einsum("nk,nkc->nc", wgt, ver)
+        e1, e2 = ver[:, 1] - ver[:, 0], ver[:, 2] - ver[:, 0]
+        nrm = np.cross(e1, e2)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        ang = rng.uniform(0, 2 * np.pi, (per, 1))
+        e1n = e1 / np.linalg.norm(e1, axis=1, keepdims=True)
+        inplane = np.cos(ang) * e1n + np.sin(ang) * np.cross(nrm, e1n)
+        d = inplane - nrm * 10.0 ** rng.uniform(-7, -1, (per, 1))
+        org = target - d * 10.0 ** rng.uniform(-1.5, 1.0, (per, 1))
+        wo = org @ m4[:3, :3] + m4[3, :3]
+        wd = d @ m4[:3, :3]
+        wd /= np.linalg.norm(wd, axis=1, keepdims=True)
+        rays.append(np.concatenate([wo, wd], 1))
+    rays = np.ascontiguousarray(np.concatenate(rays), np.float32)
+    ref, _ = oracle_mod.OracleScene(sd).intersect(rays)
+    assert 0.2 < (ref["triangle"] >= 0).mean() < 0.98
+    sb = device.SceneBuffers(gpu_ctx, sd)
+    for mode in (1, 2, 3):
+        p = device.PathTracingPass(gpu_ctx, 16, 16)
+        p.bind_scene(sb)
+        p.set_traversal(mode)
+        _check(device.trace_rays(p, rays), ref)
+        assert (p.stats()["flat_leaves"] > 0) == (mode == 3)
+        p.destroy()
+    sb.release()
