@@ -256,9 +256,11 @@ def main():
         st = p.stats(reset=True)
         if args.dump and rank == 0:
             np.savez(args.dump, **p.download())
-        units_per_rank = dict(rays=st["rays_extend"] + st["rays_shadow"], samples=st["samples"],
-                              rays_extend=st["rays_extend"], rays_shadow=st["rays_shadow"],
-                              retraced=st["rays_retraced"])
+        # rays = queries that were TRACED: the reference's occlusion queries for light samples that are exactly
+        # zero (pt_stats.rays_shadow_null) are decided without a traversal and not counted as work done
+        units_per_rank = dict(rays=st["rays_extend"] + st["rays_shadow"] - st["rays_shadow_null"], samples=st["samples"],
+                              rays_extend=st["rays_extend"], rays_shadow=st["rays_shadow"] - st["rays_shadow_null"],
+                              shadow_null=st["rays_shadow_null"], retraced=st["rays_retraced"])
         # Per-kernel times: the same draws once more, one at a time (overlapping draws would
         # be charged each other's time), bracketed by HIP events on the launching stream.
         prof = dominant = None
@@ -301,7 +303,7 @@ def main():
             dominant = ("path_trace_fast_kernel + extend_fast_kernel + extend_kernel",
                         prof["extend_ms"] + prof["trace_ms"] + prof["shadow_ms"],
                         prof["extend_launches"] + prof["trace_launches"] + prof["shadow_launches"],
-                        pst["rays_extend"] + pst["rays_shadow"])
+                        pst["rays_extend"] + pst["rays_shadow"] - pst["rays_shadow_null"])
 
 
     # max time over ranks, sum of units over ranks
@@ -346,6 +348,10 @@ def main():
             "retraced_fraction_of_extend_rays": (units_per_rank.get("retraced", 0) / units_per_rank["rays_extend"])
                                                 if units_per_rank.get("rays_extend") else None,
             "rays_per_sample": (total_rays / total_samples) if total_samples else None,
+            # rank 0's share: occlusion queries the reference issues for light samples that are exactly zero; the
+            # pass decides them without a traversal and `value` does not count them
+            "reference_shadow_rays_not_traced_per_sample": (units_per_rank.get("shadow_null", 0) / units_per_rank["samples"])
+                                                           if units_per_rank.get("samples") else None,
             "setup_s": setup_s,
             # not part of `value`: what it costs to hand the scene over from host memory once
             "host_to_device": {"bytes": int(upload_bytes), "seconds": upload_s,

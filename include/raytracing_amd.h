@@ -179,7 +179,7 @@ int pt_pass_output(pt_pass *pass, int which, pt_buf **out);
 typedef struct pt_stats {
     uint64_t samples;        /* pixels shaded (one per pixel per draw)            */
     uint64_t rays_extend;    /* closest-hit queries: primary + indirect           */
-    uint64_t rays_shadow;    /* occlusion queries: sky NEE + light shadow rays    */
+    uint64_t rays_shadow;    /* occlusion queries: sky NEE + light shadow rays (rays_shadow_null of them not traced) */
     uint64_t draws;
     uint64_t rays_retraced;  /* closest-hit queries the ordered traversal handed to the reference-order one */
     /* How often the pass re-laid out its traversal arrays since it was created: the mesh
@@ -195,6 +195,10 @@ typedef struct pt_stats {
     /* (instance, triangle) pairs in the flattened tree the ordered traversal currently walks (see
      * pt_pass_set_traversal), 0 while it walks the two levels.  Not reset. */
     uint64_t flat_leaves;
+    /* Occlusion queries of the reference (counted in rays_shadow) that were decided without a traversal: sky light
+     * samples that are +0 in every component (a direction below the surface of a conductor), which change no output
+     * whether they are visible or not (shader/pathtracing.glsl:516-528 traces them first and evaluates afterwards). */
+    uint64_t rays_shadow_null;
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 

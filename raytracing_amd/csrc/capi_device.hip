@@ -1264,9 +1264,10 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     memset(out, 0, sizeof *out);
     out->samples = raw[0];
     out->rays_extend = raw[1];
-    out->rays_shadow = raw[2];
+    out->rays_shadow = raw[2] + raw[5];  // (traced ones + those decided without a traversal)
     out->draws = raw[3];
     out->rays_retraced = raw[4];
+    out->rays_shadow_null = raw[5];
     out->mesh_level_builds = pass->mesh_level_builds;
     out->flat_leaves = pass->flat_valid ? (uint64_t)pass->flat.n_leaves : 0;
     out->reference_order_forced = pass->mesh_level_valid && pass->scene_level_valid && !(pass->mesh_level.nested && pass->scene_level.nested) ? 1 : 0;

@@ -67,8 +67,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
                                                             unsigned *count_out, unsigned *shadow_queue,
                                                             unsigned *shadow_count) {
     __shared__ __align__(16) unsigned s_V[SOBOL_NIBBLE_WORDS];
+    __shared__ unsigned s_null;  // light samples of this block that needed no occlusion query
     const unsigned n = *count_in;
     if(blockIdx.x * blockDim.x >= n && blockIdx.x != 0) return;  // (late bounces fill few blocks; block 0 books the counters)
+    if(threadIdx.x == 0) s_null = 0u;
+    unsigned my_null = 0u;
     load_sobol_to_lds(s_V);
     const unsigned nthreads = gridDim.x * blockDim.x;
 
@@ -113,8 +116,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
             __syncthreads();  // (s_slot and s_count are reused by the next round)
         }
         if(!mine) continue;
-        bool continues, has_shadow;
-        shade_vertex<RASTER>(dp, dep, i, s_V, continues, has_shadow);
+        bool continues, has_shadow, null_shadow;
+        shade_vertex<RASTER>(dp, dep, i, s_V, continues, has_shadow, null_shadow);
+        my_null += null_shadow ? 1u : 0u;
         // paths that end simply are not appended (queue compaction)
         if(has_shadow) {
             const unsigned pos = atomicAdd(shadow_count, 1u);
@@ -125,6 +129,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHA
             queue_out[pos] = i;
         }
     }
+    // one counter update per block (per wave they would queue up on one cache line: 32 K waves shade a 1080p vertex)
+    if(my_null) atomicAdd(&s_null, my_null);
+    __syncthreads();
+    if(threadIdx.x == 0 && s_null) atomicAdd(&dp.stats[5], (unsigned long long)s_null);
 }
 
 // :524-525 and :551-552 for every pending light sample of a path vertex, sky first, then the

@@ -47,7 +47,8 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 
 // Shades vertex `dep` of the path in slot i (its ray in dp.rays[i], its closest hit in dp.hits[i],
 // or, RASTER_FIRST, the raster images).  continues: the path goes on with the ray now in
-// dp.rays[i]; has_shadow: dp.shadow[..][i] holds light samples whose occlusion rays are due.
+// dp.rays[i]; has_shadow: dp.shadow[..][i] holds light samples whose occlusion rays are due;
+// null_shadow: the sky light sample is exactly zero and its occlusion query is not due (the caller counts it).
 // s_T: the Sobol nibble table in LDS (load_sobol_to_lds).
 // RASTER: what the raster pass's images are used for at vertex 0 (shader/pathtracing.glsl:612-628, :641, :684)
 //   0  nothing (no raster pass behind this host: depth and albedo come from the traced hit);
@@ -56,9 +57,10 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 //      depth output is the raster depth and the albedo is looked up through the raster instance index, as there.
 template <int RASTER>
 __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsigned i, const unsigned *s_T, bool &continues,
-                                             bool &has_shadow) {
+                                             bool &has_shadow, bool &null_shadow) {
     continues = false;
     has_shadow = false;
+    null_shadow = false;
     const pt_params &P = dp.p;
     const bool skyL = P.SkyboxLighting != 0, skyS = P.SkyboxSampling != 0;
     unsigned px, py;
@@ -237,7 +239,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     bRec.uvy = uvy;
     bRec.eta = 1.0f;
     const unsigned first_bit = dep == 0 ? 2u : 0u;
-    bool any_shadow = false;
+    bool any_shadow = false, null_sample = false;
     float pdf;
 
     // ---- sky light sample, :516-528 (occlusion decided later by the shadow stage)
@@ -250,12 +252,22 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
                 bRec.wo = to_local(coord, gwo);
                 const V3 fr = cx.eval_material(bRec);
                 recv = cx.get_background_color(gwo) * fr * fabsf(bRec.wo.z) / (pdf + cx.pdf_material(bRec));
-                flags = 1u | first_bit;
-                any_shadow = true;
+                // A sample that is +0 in every component (a direction below the surface of a conductor: half of what
+                // an importance-sampled sky offers a wall) changes nothing whether it is visible or not: x + (+-0) = x
+                // for every x the accumulator can hold (it starts as +0), and the direct light of vertex 0 starts as
+                // the +0 it would be set to.  Its occlusion query is counted, not traced -- unless the throughput is
+                // not finite (0 * inf is NaN in the reference's sum).
+                null_sample = (__float_as_uint(recv.x) | __float_as_uint(recv.y) | __float_as_uint(recv.z)) == 0u &&
+                              fabsf(history.x) <= 3.4028235e38f && fabsf(history.y) <= 3.4028235e38f && fabsf(history.z) <= 3.4028235e38f;
+                if(!null_sample) {
+                    flags = 1u | first_bit;
+                    any_shadow = true;
+                }
             }
         }
         write_shadow(dp.shadow + i, gwo, S_INF, recv, flags);
     }
+    null_shadow = null_sample;
     // ---- analytic lights, :531-554
     for(int li = 0; li < P.lightCount; li++) {
         const LightInfo light = dp.lights[li];

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastS
         if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep0]);
     }
     unsigned *wp = s_paths[wave];
-    unsigned long long n_extend = 0, n_shadow = 0, n_redo = 0;  // wave-uniform
+    unsigned long long n_extend = 0, n_shadow = 0, n_redo = 0, n_null = 0;  // wave-uniform
     unsigned batch = blockIdx.x * waves_per_block + wave;
     const unsigned first_dynamic = gridDim.x * waves_per_block;
     for(;;) {
@@ -160,10 +160,11 @@ __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastS
         bool alive = lane < cnt;
         const unsigned slot = alive ? queue_in[base + lane] : 0u;
         for(int dep = dep0;; dep++) {
-            bool continues = false, has_shadow = false;
-            if(alive) shade_vertex<0>(dp, dep, slot, s_T, continues, has_shadow);
+            bool continues = false, has_shadow = false, null_shadow = false;
+            if(alive) shade_vertex<0>(dp, dep, slot, s_T, continues, has_shadow, null_shadow);
             alive = continues;
             const unsigned long long m_c = __ballot(continues), m_s = __ballot(has_shadow);
+            n_null += (unsigned)__popcll(__ballot(null_shadow));
             if((m_c | m_s) == 0ull) break;  // (at MAX_DEPTH shade_vertex lets no path continue)
             n_extend += (unsigned)__popcll(m_c);
             n_shadow += (unsigned)__popcll(m_s);
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastS
         if(n_extend) atomicAdd(&dp.stats[1], n_extend);
         if(n_shadow) atomicAdd(&dp.stats[2], n_shadow);
         if(n_redo) atomicAdd(&dp.stats[4], n_redo);
+        if(n_null) atomicAdd(&dp.stats[5], n_null);
     }
 }
 

@@ -240,7 +240,8 @@ class PathTracingPass:
         return dict(samples=int(s.samples), rays_extend=int(s.rays_extend), rays_shadow=int(s.rays_shadow),
                     draws=int(s.draws), rays_retraced=int(s.rays_retraced), mesh_level_builds=int(s.mesh_level_builds),
                     scene_level_builds=int(s.scene_level_builds), debug=[int(x) for x in s.debug],
-                    reference_order_forced=int(s.reference_order_forced), flat_leaves=int(s.flat_leaves))
+                    reference_order_forced=int(s.reference_order_forced), flat_leaves=int(s.flat_leaves),
+                    rays_shadow_null=int(s.rays_shadow_null))
 
     def prepare(self):
         """Validates the bound scene buffers and builds the traversal arrays now instead of inside the next draw."""

@@ -228,7 +228,9 @@ def test_sky_samples_with_a_zero_direction_component(casa, oracle_mod, gpu_ctx):
         check(p.download(), ref)
         st = p.stats()
         assert st["rays_shadow"] == n_shadow and st["rays_extend"] == n_extend, (traversal, pipeline, tail)
-        assert st["rays_retraced"] >= n_shadow * 0.9, (traversal, pipeline, tail)   # the occlusion queries, given up
+        # the occlusion queries that are traced at all (samples that are exactly zero are not), given up
+        traced = n_shadow - st["rays_shadow_null"]
+        assert traced > 1000 and st["rays_retraced"] >= traced * 0.9, (traversal, pipeline, tail)
         p.destroy()
     sb.release()
 
