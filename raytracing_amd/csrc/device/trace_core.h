@@ -156,6 +156,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
 
     bool active = false, have = false, exhausted = false, any_hit = false;
+    bool pending = false;  // the lane's ray has ended; its result is handed over when the wave refills (all such lanes at once)
     Feed feed(n_rays);
     unsigned ray_idx = 0;
     int sp = 0;
@@ -169,6 +170,10 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
 
     for(;;) {
         {
+            if(pending) {
+                sink.store(ray_idx, best);
+                pending = false;
+            }
             unsigned idx = 0;
             if(feed.take(!active, next_ray, n_rays, idx)) {
                 float o[3], d[3];
@@ -216,7 +221,7 @@ __device__ __forceinline__ void trace_persistent(const TraceScene &sc, Source &s
                     have = true;
                 } else {
                     if(best.tri < 0) best.t = RT_INF;  // (a bound is not a hit)
-                    sink.store(ray_idx, best);
+                    pending = true;
                     active = false;
                 }
             }

@@ -139,6 +139,9 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
 
     bool active = false, have = false, exhausted = false, any_hit = false;
     bool uncertain = false;  // rule (5): this ray is the reference-order kernel's
+    // A ray that has ended keeps its result in the lane until the wave refills, where the results of all the lanes
+    // that have ended since are handed over at once (instead of for one to three lanes in almost every step).
+    bool pending = false, pending_ambiguous = false;
     Feed feed(n_rays);
     unsigned ray_idx = 0;
     int sp = 0;
@@ -160,6 +163,10 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
 #endif
     for(;;) {
         {
+            if(pending) {
+                sink.store(ray_idx, best, pending_ambiguous);
+                pending = false;
+            }
             unsigned idx = 0;
             if(feed.take(!active, next_ray, n_rays, idx)) {
                 float o[3], d[3];
@@ -232,7 +239,8 @@ __device__ __forceinline__ void trace_ordered(const FastScene &sc, Source &src, 
                     if(uncertain) {  // nothing found so far counts: the second pass starts without a bound
                         best.t = RT_INF; best.tri = -1; best.inst = -1;
                     }
-                    sink.store(ray_idx, best, ambiguous);
+                    pending = true;
+                    pending_ambiguous = ambiguous;
                     active = false;
                 }
             }

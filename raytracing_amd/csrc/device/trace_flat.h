@@ -67,6 +67,11 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
 
     bool active = false, have = false, exhausted = false, any_hit = false;
     bool uncertain = false;  // rule (5) of trace_fast.h: this ray is the reference-order kernel's
+    // A ray that has ended keeps its result in the lane until the wave refills: handing results over where each ray
+    // ends runs that code -- for an occlusion query: fetch the light sample, the throughput and the accumulator, add,
+    // store, with a wait on memory -- for the one to three lanes that end in a step, in almost every step; at the
+    // refill it runs once for the two dozen lanes that have ended since.
+    bool pending = false, pending_ambiguous = false;
     Feed feed(n_rays);
     unsigned ray_idx = 0;
     int sp = 0;
@@ -82,6 +87,10 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
 
     for(;;) {
         {
+            if(pending) {
+                sink.store(ray_idx, best, pending_ambiguous);
+                pending = false;
+            }
             unsigned idx = 0;
             if(feed.take(!active, next_ray, n_rays, idx)) {
                 float o[3], d[3];
@@ -154,7 +163,8 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                     if(uncertain) {
                         best.t = RT_INF; best.tri = -1; best.inst = -1;
                     }
-                    sink.store(ray_idx, best, ambiguous);
+                    pending = true;
+                    pending_ambiguous = ambiguous;
                     active = false;
                 }
             }

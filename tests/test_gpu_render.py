@@ -57,6 +57,8 @@ def test_casa_1spp(casa, small_sky, oracle_mod, gpu_ctx, depth):
     assert st["samples"] == 160 * 90
     assert st["rays_extend"] == cnt["rays_extend"]
     assert st["rays_shadow"] == cnt["rays_shadow"]
+    # (light samples that are exactly zero -- directions below a conductor's surface -- are counted, not traced)
+    assert 0 < st["rays_shadow_null"] < st["rays_shadow"] // 2
     assert np.array_equal(out["instanceIndex"], ref["instanceIndex"])
     assert np.array_equal(out["depth"], ref["depth"])
     for k in ("normal", "motion", "albedo", "directLum", "indirectLum"):
