@@ -259,6 +259,11 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                 // The first leaf of a pair hands over to the second one, two slots on.
                 have = pair;
                 if(pair) ref = (REF_TRIANGLE << 30) | (idx + 2u);
+                // The instance's scene leaf box is asked for now, for every lane of the step: where a closer hit is
+                // found it is needed at once, and asking for it there made the wave wait on memory for one or two lanes
+                // in almost every leaf step.
+                const float4 *ip = reinterpret_cast<const float4 *>(sc.scene_buf + ((size_t)(sc.hdr.inst_base + 2u * inst) << 6));
+                const float4 b5 = ip[5], b6 = ip[6];
                 // the ray in the instance's space, as the reference forms it (pathtracing.glsl:279-281;
                 // the same expressions as the instance entry of trace_ordered)
                 const float lox = (q4.x * wox + q4.y * woy) + (q4.z * woz + q4.w);
@@ -297,8 +302,6 @@ __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sin
                             pass = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, lox, loy, loz, ldx, ldy, ldz, exact);
                         }
                         if(pass) {
-                            const float4 *ip = reinterpret_cast<const float4 *>(sc.scene_buf + ((size_t)(sc.hdr.inst_base + 2u * inst) << 6));
-                            const float4 b5 = ip[5], b6 = ip[6];
                             pass = slab_fast(b5.z, b5.w, b6.x, b6.y, b6.z, b6.w, wox, woy, woz, fast_rcp(wdx), fast_rcp(wdy), fast_rcp(wdz), tw, clear);
                             if(pass && !clear) {
                                 float exact;
