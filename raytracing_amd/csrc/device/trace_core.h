@@ -17,6 +17,7 @@
 // the CPU checker evaluates the same expressions unfused.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "device_types.h"
 
 namespace rta {
@@ -108,6 +109,17 @@ struct WaveRayFeedT {
 
 using WaveRayFeed = WaveRayFeedT<64u>;
 using SparseRayFeed = WaveRayFeedT<4u>;
+
+// The number of busy lanes below which a wave refills: the kernel's own, unless the source names one.
+template <class S, class = void>
+struct has_refill_below : std::false_type {};
+template <class S>
+struct has_refill_below<S, std::void_t<decltype(S::REFILL_BELOW)>> : std::true_type {};
+template <class S>
+constexpr int refill_below(int kernel_default) {
+    if constexpr(has_refill_below<S>::value) return S::REFILL_BELOW;
+    else return kernel_default;
+}
 
 // The same interface over a set of rays that belongs to the calling wave alone (indices
 // 0 .. n_rays-1, no counter in memory): for kernels in which a wave traces the rays of its own

@@ -56,7 +56,9 @@ namespace rta {
 template <class Feed = WaveRayFeed, class Source, class Sink>
 __device__ __forceinline__ void trace_flat(const FastScene &sc, Source &src, Sink &sink, unsigned *next_ray,
                                            unsigned n_rays, uint2 *s_stack) {
-    constexpr int REFILL_BELOW = RT_FAST_REFILL;
+    // (a source whose refill is dear -- two dependent trips to memory and the hand-over of a light sample -- may ask
+    // for fewer of them: Source::REFILL_BELOW)
+    constexpr int REFILL_BELOW = refill_below<Source>(RT_FAST_REFILL);
 #ifndef RT_FLAT_LEAF_BATCH
 #define RT_FLAT_LEAF_BATCH 12
 #endif

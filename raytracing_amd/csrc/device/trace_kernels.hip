@@ -240,7 +240,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void shadow_kernel(TraceScene sc, cons
 // one persistent launch: work item idx < n_extend is an extend ray, the rest are shadow rays.
 // Halves the number of trace launches per draw; late vertices carry few rays and each launch
 // costs at least the latency of its longest ray.
+#ifndef RT_PATH_REFILL
+#define RT_PATH_REFILL 28
+#endif
 struct PathSource {
+    static constexpr int REFILL_BELOW = RT_PATH_REFILL;  // read by the flattened tree's walk (trace_flat.h)
     ExtendSource e;
     ShadowSource s;
     unsigned n_extend;
