@@ -64,7 +64,7 @@ def parse():
                     help="pt_pass_set_tail_threshold for the timed region: -1 the library's choice, 0 no tail launch (the counter "
                          "passes of tools/run_pmc.sh use --pipeline 1 --tail 0: the launches the roofline leg times)")
     ap.add_argument("--material-grouping", type=int, default=-1, choices=[-1, 0, 1],
-                    help="pt_pass_set_material_grouping: -1 the library's choice (default: off), 0 off, 1 on")
+                    help="pt_pass_set_material_grouping: -1 the library's choice (a lone draw: escaped paths apart from vertex 1 on), 0 no grouping, 1 by material type")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank control flow on ONE GPU: all ranks use device 0, gloo backend, collectives staged through the host")
     ap.add_argument("--dump", default=None, help="rank 0 writes the final output buffers to this .npz")

@@ -262,13 +262,17 @@ int pt_pass_set_pipeline(pt_pass *pass, int draws_in_flight);
  * light; other draws run vertex by vertex throughout. */
 int pt_pass_set_tail_threshold(pt_pass *pass, int threshold);
 
-/* Grouping of paths by material type inside the shade launches; no counterpart in the reference
- * (whose fragment shader dispatches per pixel, shader/materials/materials.glsl:82-111), results do
- * not depend on it.  Every block of a shade launch first moves the paths that hit a rough
- * dielectric behind the others, so that at most one of its four waves runs both BSDFs' code.
- * -1 (default): the library's choice, currently off (on the 10 M-triangle scene with half the
- * instances dielectric it measured 1 % slower: neighbouring pixels mostly hit one instance);
- * 0: off;  1: on. */
+/* Grouping of paths inside the shade launches; no counterpart in the reference (whose fragment
+ * shader branches per pixel, shader/pathtracing.glsl:569-577, shader/materials/materials.glsl:82-111),
+ * results do not depend on it.  Every block of a shade launch first sorts its paths into two groups,
+ * so that at most one of its four waves runs the code of both.
+ * -1 (default): the library's choice: in a draw that finds no other draw of its pass on the device,
+ *     from the second path vertex on, paths that escaped to the sky behind those that hit something
+ *     (shade time -10 % on the demo scene, the draw -2.6 %; with draws in flight it does not pay);
+ * 0: no grouping;
+ * 1: at every vertex, paths that hit a rough dielectric behind the others (on a 10 M-triangle scene
+ *    with half the instances dielectric it measured 1 % slower than no grouping: neighbouring pixels
+ *    mostly hit one instance). */
 int pt_pass_set_material_grouping(pt_pass *pass, int mode);
 
 /* Per-kernel device time, measured with HIP events recorded on the launching stream around

@@ -136,7 +136,7 @@ struct pt_pass {
     unsigned *d_snapshot = nullptr;
     int tail_threshold = -1;  // pt_pass_set_tail_threshold
     bool mixed_materials = false;  // instances with different material types: the shade launch groups paths by type
-    int material_grouping = -1;    // pt_pass_set_material_grouping: -1 the library's choice (off), 0 never, 1 always
+    int material_grouping = -1;    // pt_pass_set_material_grouping: -1 the library's choice (a lone draw: escaped paths apart, from vertex 1 on), 0 never, 1 by material type, always
     unsigned *h_err = nullptr;  // host address
     unsigned *d_err_flag = nullptr;  // the same word as the device sees it
     int trace_blocks = 0;   // persistent grid of a stand-alone launch (pt_pass_intersect); also sizes the spill areas
@@ -1162,11 +1162,16 @@ int pt_pass_draw(pt_pass *p) {
         if(dep == 0 && p->last_gbuf && p->last_gbuf != L.gbuf) HIP_TRY(hipStreamWaitEvent(s, p->last_gbuf, 0));
         {
             ScopedTimer t(p, K_SHADE);
-            // (library's choice: off.  Measured on a 10 M-triangle scene with 50 % dielectric instances, 16 albedo maps,
-            // MAX_DEPTH 16 at 3840x2160: shade time +1.4 %, frame -1 % with grouping -- neighbouring pixels mostly hit
-            // the same instance already, and the grouping costs a dependent gather and two barriers per block.)
-            const bool group = p->material_grouping > 0;
-            launch_shade(s, dp, dep, q_in, cnt + CNT_QUEUE + dep, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, group);
+            // The library's choice, for a draw that is alone on the device: from vertex 1 on, every block moves the
+            // paths that escaped behind the ones that hit something (at vertex 0 the sky fills whole tiles: nothing to
+            // sort).  Shade time -10 % (demo scene) / -11 % (10 M triangles), a lone draw -2.6 %; with draws in flight
+            // the frame does not gain (0 .. +2.5 % time: the larger blocks and their barriers pack less well beside the
+            // traversal launches of the other draws), so those launches stay ungrouped.  By material type only when asked:
+            // on a 10 M-triangle scene with 50 % dielectric instances, 16 albedo maps, MAX_DEPTH 16 at 3840x2160 that
+            // measured shade time +1.4 %, frame -1 % -- neighbouring pixels mostly hit the same instance already.
+            const bool by_material = p->material_grouping > 0;
+            const bool group = by_material || (p->material_grouping < 0 && dep >= 1 && alone);
+            launch_shade(s, dp, dep, q_in, cnt + CNT_QUEUE + dep, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, group, by_material);
         }
         if(dep == 0) {
             HIP_TRY(hipEventRecord(L.gbuf, s));

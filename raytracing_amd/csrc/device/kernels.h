@@ -112,11 +112,12 @@ void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const D
                          unsigned *redo_count);
 // shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to
 // queue_out and paths with pending light samples to shadow_queue.
-// group_by_material: every block first groups its 256 paths by the material type of what they hit
-// (conductors to the front, dielectrics to the back), so that at most one of its four waves runs
-// both BSDFs' code (the reference dispatches per fragment, shader/materials/materials.glsl:82-111).
+// group: every block first sorts its 256 paths into two groups, so that at most one of its four waves runs the code
+// of both: paths that escaped (a sky lookup, shader/pathtracing.glsl:569-577) behind those that hit something, or,
+// with group_materials, dielectrics behind conductors (the reference dispatches per fragment,
+// shader/materials/materials.glsl:82-111).
 void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,
-                  unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group_by_material);
+                  unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group, bool group_materials);
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,
                          const unsigned *shadow_count);
 void launch_finalize(hipStream_t s, const DrawParams &dp);

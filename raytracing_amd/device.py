@@ -264,7 +264,8 @@ class PathTracingPass:
         check(lib.pt_pass_set_tail_threshold(self.h, int(threshold)))
 
     def set_material_grouping(self, mode):
-        """Shade launches group paths by material type: -1 the library's choice (off), 0 never, 1 always."""
+        """Grouping of paths inside the shade launches: -1 the library's choice (in a lone draw: escaped paths behind the
+        ones that hit something, from the second vertex on), 0 none, 1 by material type at every vertex."""
         check(lib.pt_pass_set_material_grouping(self.h, int(mode)))
 
     def set_profiling(self, enable=True):

@@ -93,8 +93,9 @@ def test_tail_really_runs(gpu_ctx, casa, small_sky):
 
 
 def test_material_grouping_changes_nothing(gpu_ctx, small_sky, oracle_mod):
-    """pt_pass_set_material_grouping: the shade launches move paths that hit a dielectric behind the others
-    inside every block; the frame (checked against the oracle) and the ray counts stay the same."""
+    """pt_pass_set_material_grouping: the shade launches sort the paths of every block into two groups (0: not at
+    all, 1: dielectrics behind conductors at every vertex, -1: escaped paths behind the others from vertex 1 on);
+    the frame (checked against the oracle) and the ray counts stay the same."""
     from raytracing_amd import device, scene
     sd = scene.synthetic_scene(30000, dielectric_fraction=0.5, textures=3, texture_size=64, lights=1)
     w, h, depth = 333, 187, 6          # (sizes that leave ragged blocks and tiles)
