@@ -195,9 +195,10 @@ typedef struct pt_stats {
     /* (instance, triangle) pairs in the flattened tree the ordered traversal currently walks (see
      * pt_pass_set_traversal), 0 while it walks the two levels.  Not reset. */
     uint64_t flat_leaves;
-    /* Occlusion queries of the reference (counted in rays_shadow) that were decided without a traversal: sky light
+    /* Occlusion queries of the reference (counted in rays_shadow) that were decided without a traversal: light
      * samples that are +0 in every component (a direction below the surface of a conductor), which change no output
-     * whether they are visible or not (shader/pathtracing.glsl:516-528 traces them first and evaluates afterwards). */
+     * whether they are visible or not (shader/pathtracing.glsl:516-528 and :531-554 trace them first and evaluate
+     * afterwards): the sky's at every vertex, those of analytic lights from the second vertex on. */
     uint64_t rays_shadow_null;
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);

@@ -127,9 +127,10 @@ __global__ __launch_bounds__(GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK) __attribut
             __syncthreads();  // (s_slot and s_count are reused by the next round)
         }
         if(!mine) continue;
-        bool continues, has_shadow, null_shadow;
+        bool continues, has_shadow;
+        unsigned null_shadow;
         shade_vertex<RASTER>(dp, dep, i, s_V, continues, has_shadow, null_shadow);
-        my_null += null_shadow ? 1u : 0u;
+        my_null += null_shadow;
         // paths that end simply are not appended (queue compaction)
         if(has_shadow) {
             const unsigned pos = atomicAdd(shadow_count, 1u);

@@ -48,7 +48,8 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 // Shades vertex `dep` of the path in slot i (its ray in dp.rays[i], its closest hit in dp.hits[i],
 // or, RASTER_FIRST, the raster images).  continues: the path goes on with the ray now in
 // dp.rays[i]; has_shadow: dp.shadow[..][i] holds light samples whose occlusion rays are due;
-// null_shadow: the sky light sample is exactly zero and its occlusion query is not due (the caller counts it).
+// null_shadow: how many light samples of the vertex are exactly zero, their occlusion queries not due (the caller
+// counts them).
 // s_T: the Sobol nibble table in LDS (load_sobol_to_lds).
 // RASTER: what the raster pass's images are used for at vertex 0 (shader/pathtracing.glsl:612-628, :641, :684)
 //   0  nothing (no raster pass behind this host: depth and albedo come from the traced hit);
@@ -57,10 +58,10 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 //      depth output is the raster depth and the albedo is looked up through the raster instance index, as there.
 template <int RASTER>
 __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsigned i, const unsigned *s_T, bool &continues,
-                                             bool &has_shadow, bool &null_shadow) {
+                                             bool &has_shadow, unsigned &null_shadow) {
     continues = false;
     has_shadow = false;
-    null_shadow = false;
+    null_shadow = 0u;
     const pt_params &P = dp.p;
     const bool skyL = P.SkyboxLighting != 0, skyS = P.SkyboxSampling != 0;
     unsigned px, py;
@@ -240,6 +241,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     bRec.eta = 1.0f;
     const unsigned first_bit = dep == 0 ? 2u : 0u;
     bool any_shadow = false, null_sample = false;
+    unsigned null_count = 0u;  // light samples of this vertex that are exactly zero
     float pdf;
 
     // ---- sky light sample, :516-528 (occlusion decided later by the shadow stage)
@@ -267,7 +269,6 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         }
         write_shadow(dp.shadow + i, gwo, S_INF, recv, flags);
     }
-    null_shadow = null_sample;
     // ---- analytic lights, :531-554
     for(int li = 0; li < P.lightCount; li++) {
         const LightInfo light = dp.lights[li];
@@ -286,8 +287,13 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         bRec.wo = to_local(coord, dir);
         const V3 fr = cx.eval_material(bRec);
         const V3 recv = radiance * fr * fabsf(bRec.wo.z);
-        write_shadow(dp.shadow + (size_t)(1 + li) * dp.npix + i, dir, dis2, recv, 1u | first_bit);
-        any_shadow = true;
+        // (a sample that is exactly zero -- a light behind the surface -- as for the sky's above; not at vertex 0,
+        // where a visible sample, zero or not, replaces the direct light an earlier one has set, :551-552)
+        const bool null_light = dep > 0 && (__float_as_uint(recv.x) | __float_as_uint(recv.y) | __float_as_uint(recv.z)) == 0u &&
+                                fabsf(history.x) <= 3.4028235e38f && fabsf(history.y) <= 3.4028235e38f && fabsf(history.z) <= 3.4028235e38f;
+        write_shadow(dp.shadow + (size_t)(1 + li) * dp.npix + i, dir, dis2, recv, null_light ? 0u : (1u | first_bit));
+        if(null_light) null_count++;
+        else any_shadow = true;
     }
 
     // ---- next direction, :558-565
@@ -305,6 +311,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     tp[1] = make_float4(fr.x, fr.y, fr.z, __uint_as_float(cx.rng.dim));
 
     has_shadow = any_shadow;
+    null_shadow = null_count + (null_sample ? 1u : 0u);
     continues = !(pdf <= 0.0f);  // `if(pdf <= 0) break;` -- a NaN pdf continues, as it does there
 }
 

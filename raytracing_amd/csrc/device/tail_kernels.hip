@@ -160,11 +160,12 @@ __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastS
         bool alive = lane < cnt;
         const unsigned slot = alive ? queue_in[base + lane] : 0u;
         for(int dep = dep0;; dep++) {
-            bool continues = false, has_shadow = false, null_shadow = false;
+            bool continues = false, has_shadow = false;
+            unsigned null_shadow = 0u;  // (0 or 1 here: this launch runs with the sky as the only light)
             if(alive) shade_vertex<0>(dp, dep, slot, s_T, continues, has_shadow, null_shadow);
             alive = continues;
             const unsigned long long m_c = __ballot(continues), m_s = __ballot(has_shadow);
-            n_null += (unsigned)__popcll(__ballot(null_shadow));
+            n_null += (unsigned)__popcll(__ballot(null_shadow != 0u));
             if((m_c | m_s) == 0ull) break;  // (at MAX_DEPTH shade_vertex lets no path continue)
             n_extend += (unsigned)__popcll(m_c);
             n_shadow += (unsigned)__popcll(m_s);
