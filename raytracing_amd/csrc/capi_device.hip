@@ -24,7 +24,9 @@ constexpr int CNT_REDO = 280;       // [280, 350): rays the ordered extend hande
 constexpr int CNT_NEXT_REDO = 350;  // [350, 420): next-ray counters of those launches
 constexpr int CNT_INTERSECT = 420;  // next-ray, redo count, next-ray of the redo launch
 constexpr int CNT_TAIL = 424;       // batch counter of the tail launch
-constexpr int CNT_TOTAL = 432;
+constexpr int CNT_SHADOW_REDO = 432;       // [432, 502): occlusion queries the ordered traversal left undecided, per vertex
+constexpr int CNT_NEXT_SHADOW_REDO = 502;  // [502, 572): next-ray counters of the launches that trace those
+constexpr int CNT_TOTAL = 572;
 
 struct DeviceArray {
     void *p = nullptr;
@@ -116,7 +118,7 @@ struct pt_pass {
     // the first vertex, and the running mean in finalize.
     struct Lane {
         hipStream_t stream = nullptr;
-        DeviceArray rays, hits, thr, acc, shadow, queue_a, queue_b, queue_s, queue_r, counters, spill;
+        DeviceArray rays, hits, thr, acc, shadow, queue_a, queue_b, queue_s, queue_r, queue_sr, counters, spill;
         int shadow_capacity = 0;
         int spill_depth = 0;
         hipEvent_t done = nullptr, gbuf = nullptr, fin = nullptr, start = nullptr;
@@ -575,7 +577,7 @@ void release_lane(pt_pass::Lane &l) {
             (void)hipEventDestroy(*e);
             *e = nullptr;
         }
-    DeviceArray *arrs[] = {&l.rays, &l.hits, &l.thr, &l.acc, &l.shadow, &l.queue_a, &l.queue_b, &l.queue_s, &l.queue_r, &l.counters, &l.spill};
+    DeviceArray *arrs[] = {&l.rays, &l.hits, &l.thr, &l.acc, &l.shadow, &l.queue_a, &l.queue_b, &l.queue_s, &l.queue_r, &l.queue_sr, &l.counters, &l.spill};
     for(DeviceArray *a : arrs) a->release();
     l = pt_pass::Lane();
 }
@@ -606,6 +608,8 @@ int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow) {
     if(n_shadow > l.shadow_capacity) {
         HIP_TRY(hipStreamSynchronize(l.stream));
         int rc = l.shadow.ensure(npix * n_shadow * sizeof(ShadowEntry));
+        // (with analytic lights: the occlusion queries of one vertex that the ordered traversal leaves undecided)
+        if(!rc && n_shadow > 1) rc = l.queue_sr.ensure(npix * (size_t)n_shadow * 4);
         if(rc) return rc;
         l.shadow_capacity = n_shadow;
     }
@@ -1187,10 +1191,19 @@ int pt_pass_draw(pt_pass *p) {
                                  cnt + CNT_NEXT_REDO + dep + 1);
             } else {
                 {
-                    // (analytic lights, or the reference's order asked for: occlusion queries in the reference's order)
+                    // (analytic lights: the ordered traversal, what it leaves undecided in the reference's order behind it;
+                    // the reference's order asked for: all of them in that order)
                     ScopedTimer t(p, K_SHADOW);
-                    launch_shadow(s, sc, grid, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
-                                  cnt + CNT_NEXT + 2 * dep + 1);
+                    if(ordered && n_shadow > 1) {
+                        unsigned *qsr = static_cast<unsigned *>(L.queue_sr.p);
+                        launch_shadow_fast(s, fsc, grid, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
+                                           cnt + CNT_NEXT + 2 * dep + 1, qsr, cnt + CNT_SHADOW_REDO + dep);
+                        launch_shadow_redo(s, sc, p->redo_blocks, qs, dp.rays, dp.shadow, n_shadow, (int)npix, qsr,
+                                           cnt + CNT_SHADOW_REDO + dep, cnt + CNT_NEXT_SHADOW_REDO + dep);
+                    } else {
+                        launch_shadow(s, sc, grid, qs, cnt + CNT_SHADOW + dep, dp.rays, dp.shadow, n_shadow, (int)npix,
+                                      cnt + CNT_NEXT + 2 * dep + 1);
+                    }
                 }
                 extend(dep + 1, q_out);
             }

@@ -90,6 +90,14 @@ void launch_extend_fast(hipStream_t s, const FastScene &sc, int blocks, const un
 // shadow stage: ray (q, k) for q < *count, k < n_shadow; marks visible entries
 void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
                    const PathRay *rays, ShadowEntry *shadow, int n_shadow, int npix, unsigned *next_counter);
+// the same through the ordered traversal; work items it leaves undecided are listed in redo[0 .. *redo_count) and
+// traced in the reference's order by launch_shadow_redo
+void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                        const PathRay *rays, ShadowEntry *shadow, int n_shadow, int npix, unsigned *next_counter, unsigned *redo,
+                        unsigned *redo_count);
+void launch_shadow_redo(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const PathRay *rays,
+                        ShadowEntry *shadow, int n_shadow, int npix, const unsigned *redo, const unsigned *redo_count,
+                        unsigned *next_counter);
 // reference-order pass over what launch_path_trace_fast left undecided: extend rays (entries are path slots) and,
 // tagged with bit 31, sky occlusion queries, whose light sample is applied where the query ends
 void launch_path_redo(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,

@@ -233,6 +233,46 @@ __global__ __launch_bounds__(TRACE_BLOCK) void shadow_kernel(TraceScene sc, cons
     trace_persistent(sc, src, sink, next_counter, *count * (unsigned)n_shadow, s_stack);
 }
 
+// The same work items through the ordered traversal (a vertex with analytic lights): the sky's sample is an occlusion
+// query, a light's sample asks for the closest hit, whose distance is compared with the light's (ShadowSink).  What
+// the ordered traversal leaves undecided is listed by work item and traced in the reference's order behind it.
+struct ShadowSinkFast {
+    ShadowSink base;
+    unsigned *redo, *redo_count;
+    __device__ void store(unsigned idx, const LaneHit &h, bool ambiguous) const {
+        if(ambiguous) redo[atomicAdd(redo_count, 1u)] = idx;
+        else base.store(idx, h);
+    }
+};
+template <int MODE>
+__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_fast_kernel(FastScene sc, const unsigned *queue, const unsigned *count,
+                                                                 const PathRay *rays, ShadowEntry *shadow, int n_shadow, int npix,
+                                                                 unsigned *next_counter, unsigned *redo, unsigned *redo_count) {
+    __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
+    ShadowSource src{queue, rays, shadow, n_shadow, npix};
+    ShadowSinkFast sink{ShadowSink{queue, shadow, n_shadow, npix}, redo, redo_count};
+    trace_fast_any<MODE>(sc, src, sink, next_counter, *count * (unsigned)n_shadow, s_stack);
+}
+struct ShadowRedoSource {
+    ShadowSource s;
+    const unsigned *redo;
+    __device__ float bound(unsigned) const { return RT_INF; }
+    __device__ bool load(unsigned i, float o[3], float d[3], bool &any_hit) const { return s.load(redo[i], o, d, any_hit); }
+};
+struct ShadowRedoSink {
+    ShadowSink s;
+    const unsigned *redo;
+    __device__ void store(unsigned i, const LaneHit &h) const { s.store(redo[i], h); }
+};
+__global__ __launch_bounds__(TRACE_BLOCK) void shadow_redo_kernel(TraceScene sc, const unsigned *queue, const PathRay *rays,
+                                                                  ShadowEntry *shadow, int n_shadow, int npix, const unsigned *redo,
+                                                                  const unsigned *redo_count, unsigned *next_counter) {
+    __shared__ uint2 s_stack[LDS_STACK * TRACE_BLOCK];
+    ShadowRedoSource src{ShadowSource{queue, rays, shadow, n_shadow, npix}, redo};
+    ShadowRedoSink sink{ShadowSink{queue, shadow, n_shadow, npix}, redo};
+    trace_persistent<SparseRayFeed>(sc, src, sink, next_counter, *redo_count, s_stack);
+}
+
 // ---- shadow rays of vertex d and extend rays of vertex d+1 in ONE launch ---------------------
 // Both are produced by shade(d) and neither reads what the other writes (shadow rays start at
 // the origin of the new ray, extend writes hits, a visible light sample goes straight into its
@@ -384,6 +424,20 @@ void launch_shadow(hipStream_t s, const TraceScene &sc, int blocks, const unsign
                    const PathRay *rays, ShadowEntry *shadow, int n_shadow, int npix, unsigned *next_counter) {
     hipLaunchKernelGGL(shadow_kernel, dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, queue, count, rays, shadow,
                        n_shadow, npix, next_counter);
+}
+
+void launch_shadow_fast(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *count,
+                        const PathRay *rays, ShadowEntry *shadow, int n_shadow, int npix, unsigned *next_counter, unsigned *redo,
+                        unsigned *redo_count) {
+    hipLaunchKernelGGL(RT_PICK_FAST(shadow_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, count, rays, shadow,
+                       n_shadow, npix, next_counter, redo, redo_count);
+}
+
+void launch_shadow_redo(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const PathRay *rays,
+                        ShadowEntry *shadow, int n_shadow, int npix, const unsigned *redo, const unsigned *redo_count,
+                        unsigned *next_counter) {
+    hipLaunchKernelGGL(shadow_redo_kernel, dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, queue, rays, shadow, n_shadow, npix, redo,
+                       redo_count, next_counter);
 }
 
 void launch_path_redo(hipStream_t s, const TraceScene &sc, int blocks, const unsigned *queue, const unsigned *count,
