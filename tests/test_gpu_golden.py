@@ -1,0 +1,143 @@
+"""The HIP pass against the fixtures that were made FROM THE REFERENCE'S OWN CODE, with no oracle in
+between (the oracle is pinned to the same fixtures by tests/test_oracle.py on the CPU; here the
+chain reference -> HIP closes on the GPU box directly):
+
+  - tests/golden/glsl_frame_casa.npz: the seven outputs of the reference's whole fragment shader
+    (shader/pathtracing.glsl:585-691 with everything it includes) run as C++, eight configurations;
+  - tests/golden/casa_rays.npz: (instance, triangle, t) of BVHNode::rayIntersect
+    (src/BVH.cpp:89-114 + src/Intersection.cpp:8-36), the reference's CPU ray caster, compiled unmodified;
+  - tests/golden/casa_bvh.json: SHA-256 of the node array BVHNode::build (src/BVH.cpp:11-82)
+    produces for the demo scene's 19 meshes.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_oracle import GLSL_FRAME_CASES
+
+pytestmark = pytest.mark.gpu
+
+GBUF_NAMES = ("depthGBufferTexture", "normalGBufferTexture", "uvGBufferTexture", "instanceIndexGBufferTexture")
+
+
+def words_equal(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+@pytest.mark.parametrize("tag", sorted(GLSL_FRAME_CASES))
+def test_hip_pass_equals_frames_of_the_reference_shader(gpu_ctx, casa, tag):
+    """`fixed` arrays: the shader's sin / cos / atan / asin / pow resolved to the fp32 recipe the HIP
+    kernels use -> every output word must be equal.  `libm` arrays: the C library's transcendentals
+    (another driver's): the shares of pixels within 1e-3 that tests/test_oracle.py asserts for the
+    oracle must hold for the HIP pass as well."""
+    from raytracing_amd import device, scene
+    kind, w, h, max_depth, spp, switches = GLSL_FRAME_CASES[tag]
+    k = np.load(os.path.join(GOLDEN, "glsl_frame_casa.npz"))
+    if kind == "casa":
+        sd, camera = casa, scene.casa_camera()
+    else:
+        sd, camera = scene.synthetic_scene(6000, dielectric_fraction=0.5, lights=2, textures=3, texture_size=32), scene.synthetic_camera()
+    sky = scene.procedural_sky(256, 128)
+    sb = device.SceneBuffers(gpu_ctx, sd, sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    tex = []
+    with_raster = "%s_gbuf_depth" % tag in k.files
+    if with_raster:
+        images = dict(depthGBufferTexture=k["%s_gbuf_depth" % tag], instanceIndexGBufferTexture=k["%s_gbuf_inst" % tag])
+        if "%s_gbuf_normal" % tag in k.files:
+            images["normalGBufferTexture"] = k["%s_gbuf_normal" % tag]
+            images["uvGBufferTexture"] = k["%s_gbuf_uv" % tag]
+        for name in GBUF_NAMES:
+            if name in images:
+                t = device.Texture(gpu_ctx, np.ascontiguousarray(images[name], np.float32))
+                p.bind_texture(name, t)
+                tex.append(t)
+    jit = scene.mt19937_jitters(spp)
+    for s in range(1, spp + 1):
+        p.set_params(scene.make_params(w, h, camera, sky, spp=s, frame=1, jitter=jit[s - 1], max_depth=max_depth,
+                                       light_count=len(sd.lights), **switches))
+        p.draw()
+    got = p.download()
+    st = p.stats()
+    p.destroy()
+    for t in tex:
+        t.release()
+    sb.release()
+    assert st["draws"] == spp and st["reference_order_forced"] == 0
+    for name in ("albedo", "motion", "normal", "instanceIndex", "directLum", "indirectLum") + (("depth",) if with_raster else ()):
+        same = words_equal(got[name].reshape(h, w, -1), k["%s_fixed_%s" % (tag, name)])
+        assert same.all(), "%s %s: %d words differ from the reference shader's" % (tag, name, int((~same).sum()))
+    # without raster images behind it the pass writes the traced distance where the shader wrote the
+    # (LINEAR-filtered) raster depth: equal away from silhouettes
+    d = np.abs(got["depth"].reshape(h, w, 1).astype(np.float64) - k["%s_fixed_depth" % tag])
+    assert np.mean(d <= 1e-5 * np.abs(k["%s_fixed_depth" % tag])) > 0.97
+    for name, share in (("albedo", 1.0), ("directLum", 0.999), ("indirectLum", 0.99)):
+        a, b = got[name].reshape(h, w, -1).astype(np.float64), k["%s_libm_%s" % (tag, name)].astype(np.float64)
+        rel = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+        rel[np.isnan(a) & np.isnan(b)] = 0.0
+        ok = np.nan_to_num(rel, nan=1.0).max(axis=2) < 1e-3
+        assert ok.mean() >= share, (tag, name, float(ok.mean()))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_hip_closest_hits_equal_the_compiled_reference_ray_caster(gpu_ctx, casa, mode):
+    """pt_pass_intersect in every traversal mode (flattened tree, reference order, two levels) against
+    what BVHNode::rayIntersect returned for the same 4 102 rays: ids equal, t bit-equal (the bar for t
+    is 1e-5 relative)."""
+    from raytracing_amd import device
+    g = np.load(os.path.join(GOLDEN, "casa_rays.npz"))
+    sb = device.SceneBuffers(gpu_ctx, casa)
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    p.bind_scene(sb)
+    p.set_traversal(mode)
+    hits = device.trace_rays(p, g["rays"])
+    if mode == 0:
+        hits = device.trace_rays(p, g["rays"])          # the second call walks the flattened tree
+        assert p.stats()["flat_leaves"] > 0
+    p.destroy()
+    sb.release()
+    assert (g["triangle"] >= 0).sum() > 900
+    assert np.array_equal(hits["triangle"], g["triangle"])
+    assert np.array_equal(hits["instance"], g["instance"])
+    assert np.array_equal(hits["t"].view(np.uint32), g["t"].view(np.uint32))
+    rel = np.abs(hits["t"].astype(np.float64) - g["t"]) / np.maximum(np.abs(g["t"]), 1e-30)
+    assert rel.max() <= 1e-5
+
+
+def test_mesh_bvh_of_the_library_equals_the_reference_build():
+    """pt_host_build_mesh_bvh through the C ABI on the demo scene, hashed against the node array the
+    reference's compiled builder produced (run on the GPU box too, so that the driver's record shows it)."""
+    from raytracing_amd import scene
+    from conftest import CASA
+    g = json.load(open(os.path.join(GOLDEN, "casa_bvh.json")))
+    sd = scene.casa_scene(CASA)
+    raw = sd.mesh_nodes.tobytes()
+    assert hashlib.sha256(sd.triangles.tobytes()).hexdigest() == g["triangles_sha256"]
+    assert len(sd.mesh_nodes) == g["n_nodes"]
+    assert hashlib.sha256(raw).hexdigest() == g["mesh_nodes_sha256"]
+    assert [int(x) for x in sd.mesh_siz] == g["siz"] and [int(x) for x in sd.mesh_depth] == g["depth"]
+
+
+# The CPU tests that pin the ORACLE to the same fixtures, run once more where the GPU tests run, so
+# that one record shows both halves of the chain (reference = oracle, reference = HIP).
+@pytest.mark.parametrize("tag", sorted(GLSL_FRAME_CASES))
+def test_oracle_equals_frames_of_the_reference_shader(casa, oracle_mod, tag):
+    import test_oracle
+    test_oracle.test_frames_of_the_reference_shader_run_as_cpp(casa, oracle_mod, tag)
+
+
+def test_oracle_bsdfs_equal_the_reference_glsl(oracle_mod):
+    import test_oracle
+    test_oracle.test_bsdfs_and_sampler_against_the_reference_glsl_compiled_as_cpp(oracle_mod)
+
+
+def test_oracle_closest_hits_equal_the_compiled_reference_ray_caster(casa, oracle_mod):
+    import test_oracle
+    test_oracle.test_closest_hit_equals_reference_picking(casa, oracle_mod)
