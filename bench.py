@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--texture-size", type=int, default=4096)
     ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
     ap.add_argument("--pipeline", type=int, default=10, help="draws in flight on the device (pt_pass_set_pipeline)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="samples per pt_pass_draw_batch call (1..16): the samples of a frame share the launches of one draw")
     ap.add_argument("--wide-nodes", type=int, default=-1, choices=[-1, 0, 1],
                     help="node format of the ordered traversal (pt_pass_set_wide_nodes): -1 library default, 0 fp32, 1 quantised")
     ap.add_argument("--hw-queues", type=int, default=16,
@@ -157,6 +159,7 @@ def main():
     p.set_tail_threshold(args.tail)
     if wl != "casa_isect":
         p.set_pipeline(args.pipeline)
+        p.reserve_batch(args.batch)
     p.prepare()   # (traversal arrays and the path state of every draw in flight: nothing is allocated inside the timed region)
     ctx.synchronize()
     upload_s = time.perf_counter() - t_up
@@ -201,16 +204,27 @@ def main():
         jit = scene.mt19937_jitters(total_spp)
         my_samples = multigpu.sample_slice(total_spp, rank, world)  # 1-based global sample indices
 
-        def draw(global_s, accum_mode):
+        def params_of(global_s, accum_mode):
             # currentspp carries the GLOBAL sample index (it seeds the sampler); with sums
             # (accum_mode 1) the accumulation weight does not depend on it
-            prm = scene.make_params(W, H, v2w, sky, spp=global_s, frame=1, jitter=jit[(global_s - 1) % total_spp],
-                                    max_depth=args.depth, light_count=len(sd.lights), accum_mode=accum_mode)
-            p.set_params(prm)
+            return scene.make_params(W, H, v2w, sky, spp=global_s, frame=1, jitter=jit[(global_s - 1) % total_spp],
+                                     max_depth=args.depth, light_count=len(sd.lights), accum_mode=accum_mode)
+
+        def draw(global_s, accum_mode):
+            p.set_params(params_of(global_s, accum_mode))
             p.draw()
 
-        for k in range(warmup):
-            draw(1 + k, 0)
+        def draw_all(samples, accum_mode):
+            """The samples in order: one pt_pass_draw each, or pt_pass_draw_batch calls of --batch samples."""
+            samples = list(samples)
+            if args.batch <= 1:
+                for s in samples:
+                    draw(s, accum_mode)
+                return
+            for k in range(0, len(samples), args.batch):
+                p.draw_batch([params_of(s, accum_mode) for s in samples[k:k + args.batch]])
+
+        draw_all(range(1, 1 + warmup), 0)
         note("warm-up draws queued")
         accum_mode = 1 if world > 1 else 0
         if world > 1:
@@ -246,8 +260,7 @@ def main():
         barrier()
         p.stats(reset=True)
         t0 = time.perf_counter()
-        for s in my_samples:
-            draw(s, accum_mode)
+        draw_all(my_samples, accum_mode)
         if world > 1:
             combine(total_spp)
         barrier()
@@ -339,6 +352,7 @@ def main():
                        "resolution": [W, H] if wl != "casa_isect" else None,
                        "triangles": int(len(sd.triangles)), "instances": int(len(sd.instances)),
                        "draws_in_flight": args.pipeline if wl != "casa_isect" else None,
+                       "samples_per_draw": args.batch if wl != "casa_isect" else None,
                        "traversal": args.traversal, "flat_leaves": p.stats()["flat_leaves"],
                        "parallelism": "sample slicing x%d, one all-reduce" % world if world > 1 else "single GPU",
                        "collective": collective if wl != "casa_isect" else None,

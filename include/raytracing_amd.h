@@ -161,6 +161,20 @@ int pt_pass_set_params(pt_pass *pass, const pt_params *params);
 /* Renderer::draw(), Renderer.cpp:30-54: one sample per pixel for the whole frame. */
 int pt_pass_draw(pt_pass *pass);
 
+/* The host loop `for spp in 1..Config::SPP` around Renderer::draw (main.cpp:169-208: per sample a new jitter and
+ * currentspp, then one draw) as ONE call: n samples of the frame (1..16), params[k] the parameter set of sample k.
+ * The sets may differ in jitter, currentspp and frameCounter only.  The outputs are, word for word, those of n
+ * pt_pass_set_params + pt_pass_draw pairs in that order: the running mean folds the samples in order, motion / depth /
+ * normal / instance index are those of the last sample.  What changes is the shape of the work: the n samples share
+ * the queues and the launches of one draw, so every launch is n times fatter and the thin late path vertices, whose
+ * launches cost the latency of their slowest ray whatever they carry, are paid once per call instead of once per
+ * sample.  Path state: about 210 bytes per pixel per sample, allocated at the first call of that size (or by
+ * pt_pass_prepare after pt_pass_reserve_batch).  Afterwards the pass's current parameters are params[n - 1]. */
+int pt_pass_draw_batch(pt_pass *pass, const pt_params *params, int n);
+/* No counterpart in the reference.  Tells pt_pass_prepare how many samples per pt_pass_draw_batch call to size the
+ * path state of every draw in flight for (1..16, default 1), so that no draw allocates. */
+int pt_pass_reserve_batch(pt_pass *pass, int n);
+
 /* output members of Renderer (Renderer.h:19-25), by the SSBO slot the shader writes
  * (pathtracing.glsl:88-110) */
 enum {

@@ -96,6 +96,8 @@ SIGNATURES = {
     "pt_pass_bind_texture": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "pt_pass_set_params": (C.c_int, [C.c_void_p, C.POINTER(PtParams)]),
     "pt_pass_draw": (C.c_int, [C.c_void_p]),
+    "pt_pass_draw_batch": (C.c_int, [C.c_void_p, C.POINTER(PtParams), C.c_int]),
+    "pt_pass_reserve_batch": (C.c_int, [C.c_void_p, C.c_int]),
     "pt_pass_output": (C.c_int, [C.c_void_p, C.c_int, c_void_pp]),
     "pt_pass_stats": (C.c_int, [C.c_void_p, C.POINTER(PtStats), C.c_int]),
     "pt_pass_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),

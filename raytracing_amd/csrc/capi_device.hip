@@ -120,6 +120,7 @@ struct pt_pass {
         hipStream_t stream = nullptr;
         DeviceArray rays, hits, thr, acc, shadow, queue_a, queue_b, queue_s, queue_r, queue_sr, counters, spill;
         int shadow_capacity = 0;
+        int batch_capacity = 0;  // samples per draw the path state is sized for
         int spill_depth = 0;
         hipEvent_t done = nullptr, gbuf = nullptr, fin = nullptr, start = nullptr;
     };
@@ -127,6 +128,7 @@ struct pt_pass {
     Lane lanes[MAX_LANES];
     int n_lanes = 3;
     int next_lane = 0;
+    int batch_reserve = 1;  // pt_pass_reserve_batch: samples per draw that pt_pass_prepare sizes the path state for
     hipEvent_t last_gbuf = nullptr, last_fin = nullptr;  // of the previous draw; null before the first
     hipStream_t cur_stream = nullptr;                    // stream the ScopedTimer records on
     DeviceArray d_counters, d_stats, d_err;  // d_err: traversal counters of RT_TRACE_STATS builds (bytes 16..47)
@@ -588,11 +590,16 @@ size_t state_slots(int w, int h) {
     return (size_t)((w + STATE_TILE_W - 1) / STATE_TILE_W) * (size_t)((h + STATE_TILE_H - 1) / STATE_TILE_H) * 64u;
 }
 
-int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow) {
-    const size_t npix = state_slots(p->W, p->H);
+int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow, int batch) {
     if(!l.stream) {
         HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         for(hipEvent_t *e : {&l.done, &l.gbuf, &l.fin, &l.start}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    if(batch > l.batch_capacity || n_shadow > l.shadow_capacity) {
+        if(batch < l.batch_capacity) batch = l.batch_capacity;
+        if(n_shadow < l.shadow_capacity) n_shadow = l.shadow_capacity;
+        const size_t npix = state_slots(p->W, p->H) * (size_t)batch;
+        HIP_TRY(hipStreamSynchronize(l.stream));
         int rc = PT_OK;
         if(!rc) rc = l.rays.ensure(npix * sizeof(PathRay));
         if(!rc) rc = l.hits.ensure(npix * sizeof(PathHit));
@@ -603,14 +610,11 @@ int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow) {
         if(!rc) rc = l.queue_s.ensure(npix * 4);
         if(!rc) rc = l.queue_r.ensure(2 * npix * 4);  // undecided extend rays and given-up occlusion queries of one vertex
         if(!rc) rc = l.counters.ensure(CNT_TOTAL * 4);
-        if(rc) return rc;
-    }
-    if(n_shadow > l.shadow_capacity) {
-        HIP_TRY(hipStreamSynchronize(l.stream));
-        int rc = l.shadow.ensure(npix * n_shadow * sizeof(ShadowEntry));
+        if(!rc) rc = l.shadow.ensure(npix * n_shadow * sizeof(ShadowEntry));
         // (with analytic lights: the occlusion queries of one vertex that the ordered traversal leaves undecided)
         if(!rc && n_shadow > 1) rc = l.queue_sr.ensure(npix * (size_t)n_shadow * 4);
         if(rc) return rc;
+        l.batch_capacity = batch;
         l.shadow_capacity = n_shadow;
     }
     if(l.spill_depth < p->spill_depth || !l.spill.p) {
@@ -1027,14 +1031,17 @@ int pt_pass_set_params(pt_pass *pass, const pt_params *params) {
     return PT_OK;
 }
 
-int pt_pass_draw(pt_pass *p) {
-    if(!p) return fail(PT_ERR_INVALID, "pt_pass_draw: null pass");
-    if(!p->have_params) return fail(PT_ERR_STATE, "pt_pass_draw: pt_pass_set_params has not been called");
+}  // extern "C"
+
+namespace {
+// One draw of `n` samples of the frame: prms[k] are the parameters of sample k (they differ in jitter, currentspp and
+// frameCounter only).  The queues and launches are shared by the samples; finalize folds them in order.
+int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     pt_ctx *ctx = p->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = prepare_scene(p);
     if(rc) return rc;
-    const pt_params &P = p->params;
+    const pt_params &P = prms[n - 1];
     if(!p->sky) return fail(PT_ERR_STATE, "pt_pass_draw: texture \"skybox\" is not bound");
     if(P.SkyboxLighting && P.SkyboxSampling && !p->sky_cache)
         return fail(PT_ERR_STATE, "pt_pass_draw: texture \"skybox_samplecache\" is not bound");
@@ -1048,11 +1055,12 @@ int pt_pass_draw(pt_pass *p) {
         if(!lb || lb->bytes < (size_t)P.lightCount * sizeof(LightInfo))
             return fail(PT_ERR_STATE, "pt_pass_draw: lightCount exceeds the bound light buffer");
     }
-    const size_t npix = state_slots(p->W, p->H);
+    const size_t npix1 = state_slots(p->W, p->H);
+    const size_t npix = npix1 * (size_t)n;  // (slot numbers fit the 28 bits the tail launch keeps them in: checked by the callers)
     const int n_shadow = 1 + P.lightCount;
     pt_pass::Lane &L = p->lanes[p->next_lane];
     p->next_lane = (p->next_lane + 1) % p->n_lanes;
-    if((rc = prepare_lane(p, L, n_shadow))) return rc;
+    if((rc = prepare_lane(p, L, n_shadow, n))) return rc;
     // A draw that finds no other draw of this pass on the device takes the full grid (a caller
     // that waits for every frame should not pay for leaving room to draws that never come).
     int grid = p->draw_blocks;
@@ -1068,6 +1076,14 @@ int pt_pass_draw(pt_pass *p) {
     dp.p = P;
     dp.tan_half_fov = std::tan(P.fov / 2.0f);
     dp.W = p->W; dp.H = p->H; dp.npix = (int)npix;
+    dp.npix1 = (int)npix1;
+    dp.batch = n;
+    for(int k = 0; k < n; k++) {
+        dp.samples[k].jitter[0] = prms[k].jitter[0];
+        dp.samples[k].jitter[1] = prms[k].jitter[1];
+        dp.samples[k].currentspp = prms[k].currentspp;
+        dp.samples[k].seed_term = prms[k].frameCounter * prms[k].currentspp * 26699u;
+    }
     dp.tiles_x = (p->W + STATE_TILE_W - 1) / STATE_TILE_W;
     dp.n_shadow = n_shadow;
     dp.materials = static_cast<const float *>(p->slots[PT_SLOT_MATERIAL]->dptr);
@@ -1230,6 +1246,56 @@ int pt_pass_draw(pt_pass *p) {
     return PT_OK;
 }
 
+int check_params(const pt_pass *pass, const pt_params *params, const char *fn) {
+    if(params->SCREEN_W != pass->W || params->SCREEN_H != pass->H)
+        return fail(PT_ERR_INVALID, std::string(fn) + ": SCREEN_W/H differ from the size the pass was created with");
+    if(params->MAX_DEPTH < 0 || params->MAX_DEPTH > MAX_PATH_DEPTH)
+        return fail(PT_ERR_INVALID, std::string(fn) + ": MAX_DEPTH must be 0.." + std::to_string(MAX_PATH_DEPTH));
+    if(params->lightCount < 0) return fail(PT_ERR_INVALID, std::string(fn) + ": negative lightCount");
+    if(params->accum_mode != 0 && params->accum_mode != 1) return fail(PT_ERR_INVALID, std::string(fn) + ": accum_mode must be 0 or 1");
+    if(params->RasterizaionFor1st && (params->WINDOW_W <= 0 || params->WINDOW_H <= 0))
+        return fail(PT_ERR_INVALID, std::string(fn) + ": RasterizaionFor1st needs positive WINDOW_W / WINDOW_H");
+    return PT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int pt_pass_draw(pt_pass *p) {
+    if(!p) return fail(PT_ERR_INVALID, "pt_pass_draw: null pass");
+    if(!p->have_params) return fail(PT_ERR_STATE, "pt_pass_draw: pt_pass_set_params has not been called");
+    return draw_samples(p, &p->params, 1);
+}
+
+int pt_pass_draw_batch(pt_pass *p, const pt_params *params, int n) {
+    if(!p || !params) return fail(PT_ERR_INVALID, "pt_pass_draw_batch: null argument");
+    if(n < 1 || n > MAX_BATCH) return fail(PT_ERR_INVALID, "pt_pass_draw_batch: n must be 1.." + std::to_string(MAX_BATCH));
+    if(state_slots(p->W, p->H) * (size_t)n >= ((size_t)1 << 28))
+        return fail(PT_ERR_INVALID, "pt_pass_draw_batch: " + std::to_string(n) + " samples of this resolution exceed 2^28 path-state slots; use fewer per call");
+    for(int k = 0; k < n; k++) {
+        int rc = check_params(p, params + k, "pt_pass_draw_batch");
+        if(rc) return rc;
+        // the samples of one frame: everything but jitter, currentspp and frameCounter is the frame's
+        pt_params a = params[k], b = params[0];
+        a.jitter[0] = b.jitter[0]; a.jitter[1] = b.jitter[1];
+        a.currentspp = b.currentspp;
+        a.frameCounter = b.frameCounter;
+        if(memcmp(&a, &b, sizeof a) != 0)
+            return fail(PT_ERR_INVALID, "pt_pass_draw_batch: the parameter sets of a batch may differ in jitter, currentspp and frameCounter only (sample " +
+                                            std::to_string(k) + " differs from sample 0 elsewhere)");
+    }
+    p->params = params[n - 1];
+    p->have_params = true;
+    return draw_samples(p, params, n);
+}
+
+int pt_pass_reserve_batch(pt_pass *pass, int n) {
+    if(!pass) return fail(PT_ERR_INVALID, "pt_pass_reserve_batch: null pass");
+    if(n < 1 || n > MAX_BATCH) return fail(PT_ERR_INVALID, "pt_pass_reserve_batch: n must be 1.." + std::to_string(MAX_BATCH));
+    pass->batch_reserve = n;
+    return PT_OK;
+}
+
 int pt_pass_set_pipeline(pt_pass *pass, int draws_in_flight) {
     if(!pass) return fail(PT_ERR_INVALID, "pt_pass_set_pipeline: null pass");
     if(draws_in_flight < 1 || draws_in_flight > pt_pass::MAX_LANES)
@@ -1319,7 +1385,7 @@ int pt_pass_prepare(pt_pass *pass) {
     // eleven device allocations, a millisecond or two inside somebody's frame)
     const int n_shadow = pass->have_params ? 1 + pass->params.lightCount : 1;
     for(int k = 0; k < pass->n_lanes; k++)
-        if((rc = prepare_lane(pass, pass->lanes[k], n_shadow))) return rc;
+        if((rc = prepare_lane(pass, pass->lanes[k], n_shadow, pass->batch_reserve))) return rc;
     return PT_OK;
 }
 

@@ -18,12 +18,25 @@ namespace rta {
 constexpr int STATE_TILE_H = 64 / STATE_TILE_W;
 static_assert(STATE_TILE_W * STATE_TILE_H == 64, "a tile is one wavefront");
 
+// A draw carries `batch` samples of the frame (the reference's host loop `for spp in 1..SPP`, main.cpp:169-208, issues
+// one draw per sample): sample k owns the path-state slots [k * npix1, (k + 1) * npix1), queues and launches are
+// shared, so every launch of the draw is `batch` times fatter.  What differs between the samples of a frame:
+struct SampleParams {
+    float jitter[2];        // pt_params.jitter of that sample
+    unsigned currentspp;    // pt_params.currentspp: weight of the running mean
+    unsigned seed_term;     // frameCounter * currentspp * 26699, the sample's part of the pixel seed (pathtracing.glsl:595-598)
+};
+constexpr int MAX_BATCH = 16;
+
 // Everything one draw needs, passed to the kernels by value.
 struct DrawParams {
-    pt_params p;
+    pt_params p;  // (jitter, currentspp, frameCounter of the draw's samples are in `samples`)
     float tan_half_fov;  // tan(fov / 2), evaluated once on the host
     int W, H;
-    int npix;     // path-state slots: whole tiles, so >= W * H (see state_pixel)
+    int npix;     // path-state slots of the draw: batch * npix1
+    int npix1;    // path-state slots of one sample: whole tiles, so >= W * H (see state_pixel)
+    int batch;    // samples in this draw, 1..MAX_BATCH
+    SampleParams samples[MAX_BATCH];
     int tiles_x;  // tiles per row
     int n_shadow;  // shadow entries per pixel = 1 (sky) + lightCount
     // scene

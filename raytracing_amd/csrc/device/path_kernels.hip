@@ -30,10 +30,10 @@ constexpr int SHADE_GROUP_BLOCK = RT_SHADE_GROUP_BLOCK;
 __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
     const unsigned nthreads = gridDim.x * blockDim.x;
     for(unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)dp.npix; i += nthreads) {
-        unsigned px, py;
+        unsigned px, py, k;
         V3 o, d;
-        if(state_pixel(dp, i, px, py)) {
-            camera_ray(dp.p, dp.tan_half_fov, px, py, o, d);
+        if(state_pixel(dp, i, px, py, k)) {
+            camera_ray(dp.p, dp.samples[k].jitter[0], dp.samples[k].jitter[1], dp.tan_half_fov, px, py, o, d);
         } else {
             // no pixel: a ray with a NaN direction ends as a miss without any traversal, and
             // shade() drops the slot
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
         a[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if(blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H);
-        atomicAdd(&dp.stats[3], 1ull);
+        atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch);
+        atomicAdd(&dp.stats[3], (unsigned long long)dp.batch);
         dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
     }
 }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK) __attribut
 
     if(blockIdx.x == 0 && threadIdx.x == 0) {
         // (with RasterizaionFor1st the first vertex comes from images: no rays were traced for it)
-        if(RASTER != 1) atomicAdd(&dp.stats[1], dep == 0 ? (unsigned long long)dp.W * (unsigned long long)dp.H : (unsigned long long)n);
+        if(RASTER != 1) atomicAdd(&dp.stats[1], dep == 0 ? (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch : (unsigned long long)n);
         if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
     }
 
@@ -181,42 +181,52 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shadow_apply_kernel(DrawParams dp
     if(traced) atomicAdd(&dp.stats[2], traced);
 }
 
-// :633-649 and :657-680
+// :633-649 and :657-680, for the samples of the draw in their order: one thread per pixel folds them into the outputs
+// one after the other, as consecutive draws of one sample each would
 __global__ __launch_bounds__(SHADE_BLOCK) void finalize_kernel(DrawParams dp) {
     const pt_params &P = dp.p;
     const unsigned nthreads = gridDim.x * blockDim.x;
-    for(unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)dp.npix; i += nthreads) {
-        unsigned px, py;
-        if(!state_pixel(dp, i, px, py)) continue;
-        const float4 *a = reinterpret_cast<const float4 *>(dp.acc + i);
-        const float4 a0 = a[0], a1 = a[1], a2 = a[2];
-        V3 resultDI = v3(a0.x, a0.y, a0.z), resultGI = v3(a1.x, a1.y, a1.z);
-        const bool first_exist = a0.w != 0.0f;
-        if(any_nan(resultDI)) resultDI = v3(0.0f);
-        if(any_nan(resultGI)) resultGI = v3(0.0f);
-        V3 resultIDI = resultGI - resultDI;
-        V3 albedo = first_exist ? v3(a2.x, a2.y, a2.z) : resultGI;
-        resultDI = resultDI / vmax(v3(S_EPS), albedo);
-        resultIDI = resultIDI / vmax(v3(S_EPS), albedo);
+    for(unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)dp.npix1; i += nthreads) {
+        unsigned px, py, k0;
+        if(!state_pixel(dp, i, px, py, k0)) continue;
         const size_t o3 = ((size_t)py * (unsigned)dp.W + px) * 3;
-        if(P.currentspp != 1u) {
-            const V3 lastdi = v3(dp.o_direct[o3], dp.o_direct[o3 + 1], dp.o_direct[o3 + 2]);
-            const V3 lastidi = v3(dp.o_indirect[o3], dp.o_indirect[o3 + 1], dp.o_indirect[o3 + 2]);
-            const V3 lastalbedo = v3(dp.o_albedo[o3], dp.o_albedo[o3 + 1], dp.o_albedo[o3 + 2]);
-            if(P.accum_mode == 1) {
-                resultDI = lastdi + resultDI;
-                resultIDI = lastidi + resultIDI;
-                albedo = lastalbedo + albedo;
-            } else {
-                const float w = 1.0f / (float)P.currentspp;
-                resultDI = mixv(lastdi, resultDI, w);
-                resultIDI = mixv(lastidi, resultIDI, w);
-                albedo = mixv(lastalbedo, albedo, w);
+        V3 outDI = v3(0.0f), outIDI = v3(0.0f), outAlbedo = v3(0.0f);
+        bool have = false;  // the outputs' values are in registers
+        for(int k = 0; k < dp.batch; k++) {
+            const float4 *a = reinterpret_cast<const float4 *>(dp.acc + (size_t)k * (unsigned)dp.npix1 + i);
+            const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+            V3 resultDI = v3(a0.x, a0.y, a0.z), resultGI = v3(a1.x, a1.y, a1.z);
+            const bool first_exist = a0.w != 0.0f;
+            if(any_nan(resultDI)) resultDI = v3(0.0f);
+            if(any_nan(resultGI)) resultGI = v3(0.0f);
+            V3 resultIDI = resultGI - resultDI;
+            V3 albedo = first_exist ? v3(a2.x, a2.y, a2.z) : resultGI;
+            resultDI = resultDI / vmax(v3(S_EPS), albedo);
+            resultIDI = resultIDI / vmax(v3(S_EPS), albedo);
+            const unsigned spp = dp.samples[k].currentspp;
+            if(spp != 1u) {
+                if(!have) {
+                    outDI = v3(dp.o_direct[o3], dp.o_direct[o3 + 1], dp.o_direct[o3 + 2]);
+                    outIDI = v3(dp.o_indirect[o3], dp.o_indirect[o3 + 1], dp.o_indirect[o3 + 2]);
+                    outAlbedo = v3(dp.o_albedo[o3], dp.o_albedo[o3 + 1], dp.o_albedo[o3 + 2]);
+                }
+                if(P.accum_mode == 1) {
+                    resultDI = outDI + resultDI;
+                    resultIDI = outIDI + resultIDI;
+                    albedo = outAlbedo + albedo;
+                } else {
+                    const float w = 1.0f / (float)spp;
+                    resultDI = mixv(outDI, resultDI, w);
+                    resultIDI = mixv(outIDI, resultIDI, w);
+                    albedo = mixv(outAlbedo, albedo, w);
+                }
             }
+            outDI = resultDI; outIDI = resultIDI; outAlbedo = albedo;
+            have = true;
         }
-        dp.o_direct[o3] = resultDI.x; dp.o_direct[o3 + 1] = resultDI.y; dp.o_direct[o3 + 2] = resultDI.z;
-        dp.o_indirect[o3] = resultIDI.x; dp.o_indirect[o3 + 1] = resultIDI.y; dp.o_indirect[o3 + 2] = resultIDI.z;
-        dp.o_albedo[o3] = albedo.x; dp.o_albedo[o3 + 1] = albedo.y; dp.o_albedo[o3 + 2] = albedo.z;
+        dp.o_direct[o3] = outDI.x; dp.o_direct[o3 + 1] = outDI.y; dp.o_direct[o3 + 2] = outDI.z;
+        dp.o_indirect[o3] = outIDI.x; dp.o_indirect[o3 + 1] = outIDI.y; dp.o_indirect[o3 + 2] = outIDI.z;
+        dp.o_albedo[o3] = outAlbedo.x; dp.o_albedo[o3 + 1] = outAlbedo.y; dp.o_albedo[o3 + 2] = outAlbedo.z;
     }
     if(dp.snapshot && blockIdx.x == 0 && threadIdx.x == 0) {
         // queue lengths of this draw for the host's choice of the next draw's tail vertex (QueueSnapshot)
@@ -266,7 +276,7 @@ void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *sh
 }
 
 void launch_finalize(hipStream_t s, const DrawParams &dp) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(shade_grid(dp.npix)), dim3(SHADE_BLOCK), 0, s, dp);
+    hipLaunchKernelGGL(finalize_kernel, dim3(shade_grid(dp.npix1)), dim3(SHADE_BLOCK), 0, s, dp);
 }
 
 }  // namespace rta

@@ -9,15 +9,15 @@
 
 namespace rta {
 
-__device__ __forceinline__ unsigned pixel_seed(const pt_params &p, unsigned px, unsigned py) {
-    return (px * 1973u + py * 9277u + p.frameCounter * p.currentspp * 26699u) | 1u;  // :595-598
+__device__ __forceinline__ unsigned pixel_seed(unsigned seed_term, unsigned px, unsigned py) {
+    return (px * 1973u + py * 9277u + seed_term) | 1u;  // :595-598, seed_term = frameCounter * currentspp * 26699
 }
 
 // camera ray, :604-608
-__device__ __forceinline__ void camera_ray(const pt_params &p, float tan_half_fov, unsigned px, unsigned py, V3 &ori,
-                                           V3 &dir) {
+__device__ __forceinline__ void camera_ray(const pt_params &p, float jitter_x, float jitter_y, float tan_half_fov, unsigned px,
+                                           unsigned py, V3 &ori, V3 &dir) {
     const int W = p.SCREEN_W, H = p.SCREEN_H;
-    float p_x = (float)px + p.jitter[0], p_y = (float)py + p.jitter[1];
+    float p_x = (float)px + jitter_x, p_y = (float)py + jitter_y;
     float disz = (float)W * 0.5f / tan_half_fov;
     const float *m = p.v2wMat;
     ori = v3(m[12], m[13], m[14]);
@@ -29,8 +29,13 @@ __device__ __forceinline__ void camera_ray(const pt_params &p, float tan_half_fo
     dir = normalize(d);
 }
 
-// slot -> pixel; false for the slots of an edge tile that lie outside the image
-__device__ __forceinline__ bool state_pixel(const DrawParams &dp, unsigned i, unsigned &px, unsigned &py) {
+// slot -> (sample of the draw, pixel); false for the slots of an edge tile that lie outside the image
+__device__ __forceinline__ bool state_pixel(const DrawParams &dp, unsigned i, unsigned &px, unsigned &py, unsigned &k) {
+    k = 0u;
+    if(dp.batch > 1) {
+        k = i / (unsigned)dp.npix1;
+        i -= k * (unsigned)dp.npix1;
+    }
     const unsigned tile = i >> 6, in = i & 63u;
     const unsigned ty = tile / (unsigned)dp.tiles_x, tx = tile - ty * (unsigned)dp.tiles_x;
     px = tx * STATE_TILE_W + in % STATE_TILE_W;
@@ -64,9 +69,11 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     null_shadow = 0u;
     const pt_params &P = dp.p;
     const bool skyL = P.SkyboxLighting != 0, skyS = P.SkyboxSampling != 0;
-    unsigned px, py;
-    if(!state_pixel(dp, i, px, py)) return;
+    unsigned px, py, sample_k;
+    if(!state_pixel(dp, i, px, py, sample_k)) return;
     const size_t pix = (size_t)py * (unsigned)dp.W + px;  // index into the outputs
+    // motion, depth, normal and instance index keep what the LAST sample wrote (:672-688 overwrite them per draw)
+    const bool writes_gbuffer = sample_k + 1u == (unsigned)dp.batch;
 
     const float4 *rp = reinterpret_cast<const float4 *>(dp.rays + i);
     const float4 r0 = rp[0], r1 = rp[1];
@@ -116,7 +123,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     cx.sky_h = P.SKY_H;
     cx.sky_light_sum = P.skybox_Light_SUM;
     cx.rng.T = s_T;
-    cx.rng.seed = pixel_seed(P, px, py);
+    cx.rng.seed = pixel_seed(dp.samples[sample_k].seed_term, px, py);
     cx.rng.dim = __float_as_uint(t1.w);
 
     PathAccum *acc = dp.acc + i;
@@ -140,6 +147,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
             a[1] = make_float4(bg.x, bg.y, bg.z, 0.0f);
             // motion vector of the intersection's position, :652-655: (0,0,0) of the default
             // Intersection for a traced miss, ori + dir * depth for an uncovered raster pixel
+            if(!writes_gbuffer) return;
             const V3 mp = raster0 ? ray_o + ray_d * hit_t : v3(0.0f);
             const float *bp = P.backprojMat;
             const float nx = (bp[0] * mp.x + bp[4] * mp.y) + (bp[8] * mp.z + bp[12]);
@@ -215,18 +223,20 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         acc->albedo[1] = albedo.y;
         acc->albedo[2] = albedo.z;
         acc->first_exist = 1.0f;
-        const float *bp = P.backprojMat;
-        const float nx = (bp[0] * position.x + bp[4] * position.y) + (bp[8] * position.z + bp[12]);
-        const float ny = (bp[1] * position.x + bp[5] * position.y) + (bp[9] * position.z + bp[13]);
-        const float nw = (bp[3] * position.x + bp[7] * position.y) + (bp[11] * position.z + bp[15]);
-        const float suv_x = ((float)px + 0.5f) / (float)dp.W, suv_y = ((float)py + 0.5f) / (float)dp.H;
-        dp.o_motion[pix * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
-        dp.o_motion[pix * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
-        dp.o_depth[pix] = RASTER == 2 ? raster_depth : hit_t;
-        dp.o_normal[pix * 3] = normal.x;
-        dp.o_normal[pix * 3 + 1] = normal.y;
-        dp.o_normal[pix * 3 + 2] = normal.z;
-        dp.o_inst[pix] = (float)hit_inst;
+        if(writes_gbuffer) {
+            const float *bp = P.backprojMat;
+            const float nx = (bp[0] * position.x + bp[4] * position.y) + (bp[8] * position.z + bp[12]);
+            const float ny = (bp[1] * position.x + bp[5] * position.y) + (bp[9] * position.z + bp[13]);
+            const float nw = (bp[3] * position.x + bp[7] * position.y) + (bp[11] * position.z + bp[15]);
+            const float suv_x = ((float)px + 0.5f) / (float)dp.W, suv_y = ((float)py + 0.5f) / (float)dp.H;
+            dp.o_motion[pix * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
+            dp.o_motion[pix * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
+            dp.o_depth[pix] = RASTER == 2 ? raster_depth : hit_t;
+            dp.o_normal[pix * 3] = normal.x;
+            dp.o_normal[pix * 3 + 1] = normal.y;
+            dp.o_normal[pix * 3 + 2] = normal.z;
+            dp.o_inst[pix] = (float)hit_inst;
+        }
         if(dep >= P.MAX_DEPTH) return;
     }
 

@@ -29,6 +29,8 @@ constexpr unsigned TAIL_PPW = RT_TAIL_PATHS_PER_WAVE;  // paths a wave carries a
 static_assert(TAIL_PPW >= 1 && TAIL_PPW <= 64, "a wave carries at most one path per lane");
 constexpr int TAIL_BLOCK = 256;
 static_assert(TAIL_BLOCK == FAST_BLOCK && TAIL_BLOCK == TRACE_BLOCK, "the traversal stacks are laid out for 256 threads");
+// (the kernel's one LDS stack, sized for the ordered traversal, also serves the reference-order one)
+static_assert(LDS_STACK <= FAST_LDS_STACK, "trace_persistent indexes s_stack up to LDS_STACK entries per thread");
 
 // one word per carried path, in LDS: slot number and what shade left for it
 constexpr unsigned TP_SLOT = (1u << 28) - 1u;

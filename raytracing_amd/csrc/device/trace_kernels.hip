@@ -150,10 +150,10 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_fast_kernel(Fas
 struct PrimarySource {
     const DrawParams &dp;
     __device__ bool load(unsigned i, float o[3], float d[3], bool &any_hit) const {
-        unsigned px, py;
-        if(!state_pixel(dp, i, px, py)) return false;  // a slot of an edge tile that names no pixel: nobody reads it
+        unsigned px, py, k;
+        if(!state_pixel(dp, i, px, py, k)) return false;  // a slot of an edge tile that names no pixel: nobody reads it
         V3 ro, rd;
-        camera_ray(dp.p, dp.tan_half_fov, px, py, ro, rd);
+        camera_ray(dp.p, dp.samples[k].jitter[0], dp.samples[k].jitter[1], dp.tan_half_fov, px, py, ro, rd);
         float4 *r = reinterpret_cast<float4 *>(dp.rays + i);
         r[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);
         r[1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_fast_kernel(Fa
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
     if(blockIdx.x == 0 && threadIdx.x == 0) {
         // the books generate_kernel keeps (path_kernels.hip)
-        atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H);
-        atomicAdd(&dp.stats[3], 1ull);
+        atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch);
+        atomicAdd(&dp.stats[3], (unsigned long long)dp.batch);
         dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
     }
     PrimarySource src{dp};

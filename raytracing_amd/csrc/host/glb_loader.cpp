@@ -1,5 +1,6 @@
 // See glb_loader.h.  A small JSON reader (values kept as a tree) and the glTF walk.
 #include "glb_loader.h"
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -193,13 +194,29 @@ bool read_accessor(Ctx &c, size_t idx, int want_ncomp, bool as_index, std::vecto
     const JVal *bo = bv.get("byteOffset"), *bl = bv.get("byteLength"), *bs = bv.get("byteStride"), *ao = a.get("byteOffset"), *bb = bv.get("buffer");
     if(bb && (bb->kind != JVal::NUM || bb->num != 0)) return c.fail("only the embedded binary chunk (buffer 0) is supported");
     if(!bl || bl->kind != JVal::NUM) return c.fail("bufferView without byteLength");
-    const double off_d = (bo && bo->kind == JVal::NUM ? bo->num : 0.0) + (ao && ao->kind == JVal::NUM ? ao->num : 0.0);
-    if(off_d < 0 || off_d > (double)c.bin_bytes) return c.fail("accessor offset outside the binary chunk");
-    const size_t off = (size_t)off_d;
+    // Every quantity of the file is checked as the number it is in the JSON (a double) before it becomes a size_t:
+    // whole, non-negative, and small enough that no product below can wrap.
+    auto whole = [&](const JVal *v, double dflt, double &out_d) {
+        if(!v) { out_d = dflt; return true; }
+        if(v->kind != JVal::NUM || !(v->num >= 0) || !(v->num <= (double)c.bin_bytes) || v->num != std::floor(v->num)) return false;
+        out_d = v->num;
+        return true;
+    };
+    double bv_off_d, bv_len_d, acc_off_d, stride_d;
+    if(!whole(bo, 0.0, bv_off_d) || !whole(bl, 0.0, bv_len_d) || !whole(ao, 0.0, acc_off_d) || !whole(bs, 0.0, stride_d))
+        return c.fail("bufferView / accessor offset, length or stride is not a whole number inside the binary chunk");
+    if(cnt->num != std::floor(cnt->num)) return c.fail("accessor count is not a whole number");
+    const size_t bv_off = (size_t)bv_off_d, bv_len = (size_t)bv_len_d, acc_off = (size_t)acc_off_d;
+    if(bv_off > c.bin_bytes || bv_len > c.bin_bytes - bv_off) return c.fail("bufferView reaches beyond the binary chunk");
     const size_t elem = (size_t)csz * ncomp;
-    size_t stride = bs && bs->kind == JVal::NUM && bs->num > 0 ? (size_t)bs->num : elem;
+    const size_t stride = stride_d > 0 ? (size_t)stride_d : elem;
     if(stride < elem) return c.fail("bufferView stride smaller than the element");
-    if(count && (off + stride * (count - 1) + elem > c.bin_bytes)) return c.fail("accessor reaches beyond the binary chunk");
+    if(count) {
+        // inside the bufferView: acc_off + stride * (count - 1) + elem <= bv_len, with no product that can wrap
+        if(acc_off > bv_len || elem > bv_len - acc_off) return c.fail("accessor reaches beyond its bufferView");
+        if((count - 1) > (bv_len - acc_off - elem) / stride) return c.fail("accessor reaches beyond its bufferView");
+    }
+    const size_t off = bv_off + acc_off;
     if(fout) fout->resize(count * ncomp);
     if(iout) iout->resize(count * ncomp);
     for(size_t i = 0; i < count; i++) {
@@ -248,9 +265,14 @@ bool node_matrix(Ctx &c, const JVal &n, Mat4 &out) {
     return true;
 }
 
-bool walk(Ctx &c, size_t ni, const Mat4 &parent, bool is_root, const std::vector<int32_t> &mesh_material, GlbScene &out, int depth) {
+bool walk(Ctx &c, size_t ni, const Mat4 &parent, bool is_root, const std::vector<int32_t> &mesh_material, GlbScene &out, int depth,
+          std::vector<uint8_t> &visited) {
     const JVal *nodes = c.js->get("nodes");
-    if(depth > 256) return c.fail("node hierarchy deeper than 256 (a cycle?)");
+    if(depth > 256) return c.fail("node hierarchy deeper than 256");
+    // glTF hierarchies are strict trees: a node reached twice is a cycle or a shared child (which a small file
+    // could use to make this walk exponential)
+    if(visited[ni]) return c.fail("node " + std::to_string(ni) + " is reached twice (hierarchies must be trees)");
+    visited[ni] = 1;
     const JVal &n = nodes->arr[ni];
     Mat4 local = Mat4::identity();
     if(!is_root && !node_matrix(c, n, local)) return false;
@@ -268,7 +290,7 @@ bool walk(Ctx &c, size_t ni, const Mat4 &parent, bool is_root, const std::vector
         for(const JVal &cv : ch->arr) {
             size_t ci;
             if(!index_of(&cv, nodes->size(), ci)) return c.fail("child node index out of range");
-            if(!walk(c, ci, world, false, mesh_material, out, depth + 1)) return false;
+            if(!walk(c, ci, world, false, mesh_material, out, depth + 1, visited)) return false;
         }
     }
     return true;
@@ -408,7 +430,8 @@ bool load_glb(const uint8_t *data, size_t n, GlbScene &out, std::string &err) {
     if(!roots || roots->size() != 1) return c.fail("scenes with other than one root node get a synthetic root from the importer; not mapped");
     size_t ri;
     if(!index_of(&roots->arr[0], nodes->size(), ri)) return c.fail("root node index out of range");
-    if(!walk(c, ri, Mat4::identity(), true, mesh_material, out, 0)) return false;
+    std::vector<uint8_t> visited(nodes->size(), 0);
+    if(!walk(c, ri, Mat4::identity(), true, mesh_material, out, 0, visited)) return false;
     if(out.instances.empty()) return c.fail("no node carries a mesh");
     return true;
 }

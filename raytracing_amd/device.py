@@ -227,6 +227,16 @@ class PathTracingPass:
     def draw(self):
         check(lib.pt_pass_draw(self.h))
 
+    def draw_batch(self, params_list):
+        """pt_pass_draw_batch: the samples of one frame (parameter sets differing in jitter, currentspp, frameCounter)
+        as one draw; outputs as after set_params + draw for each in turn."""
+        arr = (_capi.PtParams * len(params_list))(*params_list)
+        check(lib.pt_pass_draw_batch(self.h, arr, len(params_list)))
+
+    def reserve_batch(self, n):
+        """Samples per draw_batch call that prepare() sizes the path state for."""
+        check(lib.pt_pass_reserve_batch(self.h, int(n)))
+
     def intersect(self, rays_buf, n, hits_buf):
         check(lib.pt_pass_intersect(self.h, rays_buf.h, n, hits_buf.h))
 

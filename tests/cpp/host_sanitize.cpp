@@ -8,6 +8,7 @@
 #include <cstring>
 #include <algorithm>
 #include <random>
+#include <string>
 #include <vector>
 #include "raytracing_amd.h"
 
@@ -267,6 +268,67 @@ int main(int argc, char **argv) {
                 read_all(junk, false);
             }
         }
+    }
+    // hand-made glTF binaries: sizes whose products wrap in size_t, an accessor that leaves its bufferView
+    // while staying inside the chunk, nodes that share children (2^40 visits if walked as a tree)
+    {
+        auto make = [](const std::string &js_in, size_t blob_bytes) {
+            std::string js = js_in;
+            while(js.size() % 4) js += ' ';
+            std::vector<uint8_t> out(12 + 8 + js.size() + 8 + blob_bytes, 0);
+            const uint32_t hdr[3] = {0x46546C67u, 2u, (uint32_t)out.size()};
+            memcpy(&out[0], hdr, 12);
+            const uint32_t jc[2] = {(uint32_t)js.size(), 0x4E4F534Au}, bc[2] = {(uint32_t)blob_bytes, 0x004E4942u};
+            memcpy(&out[12], jc, 8);
+            memcpy(&out[20], js.data(), js.size());
+            memcpy(&out[20 + js.size()], bc, 8);
+            for(size_t k = 0; k + 4 <= blob_bytes; k += 4) {   // floats 0..: positions / normals; the last 12 bytes: indices 0,1,2,2,1,3
+                const float f = (float)((k / 4) % 7);
+                memcpy(&out[28 + js.size() + k], &f, 4);
+            }
+            const uint16_t idx[6] = {0, 1, 2, 2, 1, 3};
+            memcpy(&out[28 + js.size() + blob_bytes - 12], idx, 12);
+            return out;
+        };
+        auto file_with = [&](const char *view0, const char *acc0, const char *nodes) {
+            std::string js = std::string("{\"scene\":0,\"scenes\":[{\"nodes\":[0]}],\"nodes\":") + nodes +
+                ",\"meshes\":[{\"primitives\":[{\"attributes\":{\"POSITION\":0,\"NORMAL\":1},\"indices\":2}]}],"
+                "\"bufferViews\":[" + view0 + ",{\"buffer\":0,\"byteOffset\":48,\"byteLength\":48},{\"buffer\":0,\"byteOffset\":96,\"byteLength\":12}],"
+                "\"accessors\":[" + acc0 + ",{\"bufferView\":1,\"componentType\":5126,\"count\":4,\"type\":\"VEC3\"},"
+                "{\"bufferView\":2,\"componentType\":5123,\"count\":6,\"type\":\"SCALAR\"}]}";
+            return make(js, 108);
+        };
+        const char *view_ok = "{\"buffer\":0,\"byteOffset\":0,\"byteLength\":48}";
+        const char *acc_ok = "{\"bufferView\":0,\"componentType\":5126,\"count\":4,\"type\":\"VEC3\"}";
+        const char *nodes_ok = "[{\"mesh\":0}]";
+        pt_glb *g = nullptr;
+        std::vector<uint8_t> f = file_with(view_ok, acc_ok, nodes_ok);
+        EXPECT(pt_host_glb_open_memory(f.data(), f.size(), &g) == PT_OK);
+        if(g) pt_host_glb_close(g);
+        for(const char *view : {"{\"buffer\":0,\"byteOffset\":0,\"byteLength\":48,\"byteStride\":4611686018427387904}",
+                                "{\"buffer\":0,\"byteOffset\":0,\"byteLength\":48,\"byteStride\":1e300}",
+                                "{\"buffer\":0,\"byteOffset\":18446744073709551616,\"byteLength\":48}",
+                                "{\"buffer\":0,\"byteOffset\":-8,\"byteLength\":48}",
+                                "{\"buffer\":0,\"byteOffset\":0,\"byteLength\":9223372036854775808}",
+                                "{\"buffer\":0,\"byteOffset\":0,\"byteLength\":36}",
+                                "{\"buffer\":0,\"byteOffset\":0,\"byteLength\":48,\"byteStride\":16}"}) {
+            f = file_with(view, acc_ok, nodes_ok);
+            g = nullptr;
+            EXPECT(pt_host_glb_open_memory(f.data(), f.size(), &g) != PT_OK);
+        }
+        for(const char *acc : {"{\"bufferView\":0,\"componentType\":5126,\"count\":4,\"type\":\"VEC3\",\"byteOffset\":9223372036854775808}",
+                               "{\"bufferView\":0,\"componentType\":5126,\"count\":4.5,\"type\":\"VEC3\"}",
+                               "{\"bufferView\":0,\"componentType\":5126,\"count\":5,\"type\":\"VEC3\"}"}) {
+            f = file_with(view_ok, acc, nodes_ok);
+            g = nullptr;
+            EXPECT(pt_host_glb_open_memory(f.data(), f.size(), &g) != PT_OK);
+        }
+        std::string dag = "[";
+        for(int k = 0; k < 40; k++) dag += "{\"children\":[" + std::to_string(k + 1) + "," + std::to_string(k + 1) + "]},";
+        dag += "{\"mesh\":0}]";
+        f = file_with(view_ok, acc_ok, dag.c_str());
+        g = nullptr;
+        EXPECT(pt_host_glb_open_memory(f.data(), f.size(), &g) != PT_OK);
     }
     printf(fails ? "FAILED %d\n" : "host sanitize run ok\n", fails);
     return fails ? 1 : 0;

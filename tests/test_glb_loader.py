@@ -114,3 +114,44 @@ def test_malformed_files_are_refused():
     assert "NORMAL" in _open(_glb(bad, blob))[1]
     assert _open(_glb({"asset": {}}, b""))[0] < 0
     assert _open(struct.pack("<III", 0x46546C67, 2, 40) + struct.pack("<II", 20, 0x4E4F534A) + b'{"a": [1, 2, {"b"')[0] < 0
+
+
+def test_sizes_that_would_wrap_and_shared_children_are_refused():
+    """Offsets, strides and counts are checked as the numbers the JSON holds before any product is formed
+    (a stride of 2^62 with count 5 makes 2^64 = 0 in size_t arithmetic), accessors are held inside their
+    bufferView, and a node may be reached once: a chain of nodes that each list the next one twice is a
+    few hundred bytes that would otherwise be walked 2^depth times."""
+    js, blob = _tiny()
+    for key, val in (("byteStride", 2.0 ** 62), ("byteStride", 1e300), ("byteStride", 12.5), ("byteOffset", -4),
+                     ("byteOffset", 2.0 ** 64), ("byteLength", 2.0 ** 63), ("byteLength", 1e308)):
+        bad, _ = _tiny()
+        bad["bufferViews"][0][key] = val
+        rc, msg = _open(_glb(bad, blob))
+        assert rc < 0 and "glb:" in msg, (key, val, msg)
+    bad, _ = _tiny()
+    bad["accessors"][0]["byteOffset"] = 2.0 ** 63
+    assert _open(_glb(bad, blob))[0] < 0
+    bad, _ = _tiny()
+    bad["accessors"][0]["count"] = 3.5
+    assert _open(_glb(bad, blob))[0] < 0
+    bad, _ = _tiny()
+    bad["bufferViews"][0]["byteLength"] = 36              # the accessor's 4 x 12 bytes no longer fit ITS view (they do fit the chunk)
+    assert "bufferView" in _open(_glb(bad, blob))[1]
+    bad, _ = _tiny()
+    bad["bufferViews"][2]["byteStride"] = 4               # 6 indices 4 bytes apart: 22 bytes from a 12-byte view
+    assert "bufferView" in _open(_glb(bad, blob))[1]
+    # a legal stride still reads what it should: positions 24 bytes apart = vertices 0 and 2 of the packed array
+    ok, _ = _tiny()
+    ok["bufferViews"][0]["byteStride"] = 24
+    ok["accessors"][0]["count"] = 2
+    ok["accessors"][1]["count"] = 2
+    ok["accessors"][2] = {"bufferView": 2, "componentType": 5123, "count": 3, "type": "SCALAR"}
+    blob2 = blob[:96] + np.array([0, 1, 1, 0, 0, 0], np.uint16).tobytes()
+    assert _open(_glb(ok, blob2))[0] == 0
+    # 40 levels, every node lists its child twice: 2^40 visits unless the second is refused
+    dag, _ = _tiny()
+    dag["nodes"] = [{"children": [k + 1, k + 1]} for k in range(40)] + [{"mesh": 0}]
+    import time
+    t0 = time.time()
+    rc, msg = _open(_glb(dag, blob))
+    assert rc < 0 and "twice" in msg and time.time() - t0 < 1.0

@@ -1,0 +1,143 @@
+"""pt_pass_draw_batch: the reference's host loop `for spp in 1..SPP` (main.cpp:169-208: new jitter and currentspp,
+then Renderer::draw) as one call.  Its outputs must be, word for word, those of the same samples drawn one by one
+-- which tests/test_gpu_render.py and tests/test_gpu_golden.py tie to the oracle and to the reference's shader --
+and, here too, the oracle's running mean over the same samples."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def words_equal(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def params_of(scene, sd, sky, camera, w, h, spps, depth, **kw):
+    jit = scene.mt19937_jitters(max(spps))
+    return [scene.make_params(w, h, camera, sky, spp=s, frame=1, jitter=jit[s - 1], max_depth=depth,
+                              light_count=len(sd.lights), **kw) for s in spps]
+
+
+def one_by_one(p, prms):
+    for prm in prms:
+        p.set_params(prm)
+        p.draw()
+    return p.download(), p.stats(reset=True)
+
+
+def batched(p, prms, sizes):
+    k = 0
+    for n in sizes:
+        p.draw_batch(prms[k:k + n])
+        k += n
+    assert k == len(prms)
+    return p.download(), p.stats(reset=True)
+
+
+@pytest.mark.parametrize("pipeline,tail", [(1, -1), (1, 0), (3, -1)])
+def test_batches_equal_single_draws_and_the_oracle(gpu_ctx, casa, small_sky, oracle_mod, pipeline, tail):
+    from raytracing_amd import device, scene
+    w, h, depth = 160, 90, 5
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    p.set_pipeline(pipeline)
+    p.set_tail_threshold(tail)
+    prms = params_of(scene, casa, small_sky, scene.casa_camera(), w, h, list(range(1, 12)), depth)
+    p.stats(reset=True)
+    ref, st_ref = one_by_one(p, prms)
+    # 11 samples as 4 + 1 + 6 (a batch, a batch of one, a larger batch: the path state grows), then as 3 + 8, then 11 x 1
+    for sizes in ([4, 1, 6], [3, 8], [1] * 11):
+        got, st = batched(p, prms, sizes)
+        for k in ref:
+            assert words_equal(got[k], ref[k]), (sizes, k)
+        for k in ("samples", "draws", "rays_extend", "rays_shadow", "rays_shadow_null"):
+            assert st[k] == st_ref[k], (sizes, k)
+    # and the oracle's running mean over the same samples
+    osc = oracle_mod.OracleScene(casa, small_sky)
+    acc = None
+    for prm in prms[:5]:
+        acc, _ = osc.render(prm, acc)
+    got, _ = batched(p, prms[:5], [5])
+    for k in acc:
+        assert words_equal(got[k], acc[k].reshape(got[k].shape)), k
+    p.destroy()
+    sb.release()
+
+
+def test_batch_with_lights_dielectrics_and_sums(gpu_ctx, small_sky):
+    """Analytic lights (the launches that trace occlusion queries apart from the extend rays), rough dielectrics and
+    albedo maps; accum_mode 1 (sums, as the multi-GPU slices keep them); a frame counter other than 1."""
+    from raytracing_amd import device, scene
+    sd = scene.synthetic_scene(20_000, seed=3, dielectric_fraction=0.5, lights=2, textures=2, texture_size=64)
+    w, h = 128, 72
+    sb = device.SceneBuffers(gpu_ctx, sd, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    jit = scene.mt19937_jitters(6)
+    for accum_mode in (0, 1):
+        prms = [scene.make_params(w, h, scene.synthetic_camera(), small_sky, spp=s, frame=3, jitter=jit[s - 1], max_depth=6,
+                                  light_count=len(sd.lights), accum_mode=accum_mode) for s in range(1, 7)]
+        ref, _ = one_by_one(p, prms)
+        got, _ = batched(p, prms, [6])
+        for k in ref:
+            assert words_equal(got[k], ref[k]), (accum_mode, k)
+        got, _ = batched(p, prms, [2, 4])
+        for k in ref:
+            assert words_equal(got[k], ref[k]), (accum_mode, k)
+    p.destroy()
+    sb.release()
+
+
+def test_batch_with_raster_first_inputs(gpu_ctx, casa, small_sky, oracle_mod):
+    from raytracing_amd import device, scene
+    from test_gpu_raster_first import gbuffer_from_traced_hits
+    w, h = 96, 54
+    osc = oracle_mod.OracleScene(casa, small_sky)
+    gb = gbuffer_from_traced_hits(casa, osc, scene.make_params(w, h, scene.casa_camera(), small_sky, max_depth=2), w, h)[:4]
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    tex = [device.Texture(gpu_ctx, np.ascontiguousarray(a, np.float32)) for a in gb]
+    for name, t in zip(("depthGBufferTexture", "normalGBufferTexture", "uvGBufferTexture", "instanceIndexGBufferTexture"), tex):
+        p.bind_texture(name, t)
+    jit = scene.mt19937_jitters(4)
+    prms = [scene.make_params(w, h, scene.casa_camera(), small_sky, spp=s, jitter=jit[s - 1], max_depth=3, raster_first=True)
+            for s in range(1, 5)]
+    ref, _ = one_by_one(p, prms)
+    got, _ = batched(p, prms, [4])
+    for k in ref:
+        assert words_equal(got[k], ref[k]), k
+    p.destroy()
+    for t in tex:
+        t.release()
+    sb.release()
+
+
+def test_batch_arguments_are_checked(gpu_ctx, casa, small_sky):
+    from raytracing_amd import device, scene, _capi
+    w, h = 32, 18
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    prm = scene.make_params(w, h, scene.casa_camera(), small_sky, spp=1, max_depth=2)
+    with pytest.raises(_capi.PtError, match="1..16"):
+        p.draw_batch([prm] * 17)
+    with pytest.raises(_capi.PtError, match="1..16"):
+        _capi.check(_capi.lib.pt_pass_draw_batch(p.h, (_capi.PtParams * 1)(prm), 0))
+    other = scene.make_params(w, h, scene.casa_camera(), small_sky, spp=2, max_depth=3)
+    with pytest.raises(_capi.PtError, match="jitter, currentspp and frameCounter only"):
+        p.draw_batch([prm, other])
+    bad = scene.make_params(w + 1, h, scene.casa_camera(), small_sky, spp=1, max_depth=2)
+    with pytest.raises(_capi.PtError, match="SCREEN_W"):
+        p.draw_batch([bad])
+    with pytest.raises(_capi.PtError, match="1..16"):
+        p.reserve_batch(0)
+    p.reserve_batch(4)
+    p.prepare()
+    p.draw_batch([prm] * 4)
+    gpu_ctx.synchronize()
+    p.destroy()
+    sb.release()
