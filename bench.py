@@ -13,7 +13,10 @@ One step = one pass of the hot path over one batch:
 With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds the
 whole scene and renders its own slice of the samples (global sample s belongs to rank
 (s-1) % N); accumulators are kept as sums and combined with ONE all-reduce (RCCL) at the
-end of the timed region.  Scaling is weak: every rank does K steps.
+end of the timed region.  Scaling is strong by default then: the K steps are the samples of
+ONE frame, cut over the ranks (the multi-GPU benchmark configuration: a fixed-spp frame over
+2/4/8 GPUs); --scaling weak gives every rank K steps.  The line carries the time of the
+combine (allreduce_ms) and every rank's draw time, so that a flat curve can be attributed.
 
 Prints one JSON line on rank 0.
 """
@@ -45,18 +48,18 @@ def parse():
     ap.add_argument("--textures", type=int, default=0, help="synth_pt: number of procedural RGBA8 albedo maps")
     ap.add_argument("--texture-size", type=int, default=4096)
     ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
-    ap.add_argument("--pipeline", type=int, default=10, help="draws in flight on the device (pt_pass_set_pipeline)")
-    ap.add_argument("--batch", type=int, default=1,
+    ap.add_argument("--pipeline", type=int, default=2, help="draws in flight on the device (pt_pass_set_pipeline)")
+    ap.add_argument("--batch", type=int, default=8,
                     help="samples per pt_pass_draw_batch call (1..16): the samples of a frame share the launches of one draw")
     ap.add_argument("--wide-nodes", type=int, default=-1, choices=[-1, 0, 1],
                     help="node format of the ordered traversal (pt_pass_set_wide_nodes): -1 library default, 0 fp32, 1 quantised")
-    ap.add_argument("--hw-queues", type=int, default=16,
-                    help="GPU_MAX_HW_QUEUES for this process (HIP's default of 4 holds 3 draws in flight + the main stream; "
-                         "the default pipeline of 6 needs more); 0 leaves the environment as it is.  Read once, when the HIP "
-                         "runtime starts, so under rocprofv3 export the variable instead.  Reported in config.")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every rank draws --steps samples (N x steps in all); strong = --steps samples in all, "
-                         "sliced over the ranks (the multi-GPU benchmark configuration: a fixed 256-spp frame cut over 2/4/8 GPUs)")
+    ap.add_argument("--hw-queues", type=int, default=0,
+                    help="GPU_MAX_HW_QUEUES for this process; 0 (default) leaves the environment as it is (HIP's default of 4 "
+                         "holds 3 draws in flight + the main stream; more draws in flight than that need more).  Read once, when "
+                         "the HIP runtime starts, so under rocprofv3 export the variable instead.  Reported in config.")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: strong (default) = --steps samples in all, sliced over the ranks (the multi-GPU benchmark "
+                         "configuration: a fixed-spp frame cut over 2/4/8 GPUs); weak = every rank draws --steps samples (N x steps in all)")
     ap.add_argument("--collective", default="capi", choices=["capi", "torch"],
                     help="N > 1: combine through the library's own pt_pass_allreduce (RCCL, default) or through torch.distributed")
     ap.add_argument("--traversal", type=int, default=0, choices=[0, 1, 2, 3],
@@ -91,6 +94,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started without a launcher: start one rank per GPU as child processes (before anything here
         # touches the GPU) and pass rank 0's JSON line through
@@ -178,7 +183,8 @@ def main():
         if world > 1:
             dist.barrier()
 
-    comm = collective = total_spp = None
+    comm = collective = total_spp = draw_s = combine_s = None
+    my_samples = []
     if wl == "casa_isect":
         lo, hi = sd.world_box()
         rays = scene.random_rays(lo, hi, args.rays, 7 + rank)
@@ -262,7 +268,10 @@ def main():
         t0 = time.perf_counter()
         draw_all(my_samples, accum_mode)
         if world > 1:
-            combine(total_spp)
+            ctx.synchronize()                      # this rank's slice is drawn
+            draw_s = time.perf_counter() - t0
+            combine(total_spp)                     # (waits for the collectives)
+            combine_s = time.perf_counter() - t0 - draw_s   # includes waiting for the slowest rank's slice
         barrier()
         dt = time.perf_counter() - t0
         note("timed region done")
@@ -328,6 +337,9 @@ def main():
         uu = torch.tensor([units_per_rank["rays"], units_per_rank["samples"]], dtype=torch.float64, device=red_dev)
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
         total_rays, total_samples = float(uu[0].item()), float(uu[1].item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"draw_ms": (draw_s or 0.0) * 1e3, "combine_ms": (combine_s or 0.0) * 1e3,
+                                          "samples": len(list(my_samples)) if wl != "casa_isect" else None})
     else:
         total_rays, total_samples = float(units_per_rank["rays"]), float(units_per_rank["samples"])
 
@@ -359,6 +371,10 @@ def main():
                        "total_spp": total_spp if wl != "casa_isect" else None,
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "msamples_per_s": total_samples / dt / 1e6,
+            # N > 1: the combine (one all-reduce of the 9 accumulated floats per pixel + one broadcast of the 7 last-write ones + the
+            # scale) as the fastest rank saw it -- the others' figures include waiting for the slowest slice -- and every rank's draw time
+            "allreduce_ms": min(r["combine_ms"] for r in per_rank) if world > 1 and wl != "casa_isect" else None,
+            "per_rank": per_rank if world > 1 else None,
             "retraced_fraction_of_extend_rays": (units_per_rank.get("retraced", 0) / units_per_rank["rays_extend"])
                                                 if units_per_rank.get("rays_extend") else None,
             "rays_per_sample": (total_rays / total_samples) if total_samples else None,

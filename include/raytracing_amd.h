@@ -327,8 +327,10 @@ int pt_pass_intersect(pt_pass *pass, const pt_buf *rays, size_t n, pt_buf *hits)
  * per call; trees whose traversal needs more than 48 spill entries per ray are refused
  * (PT_ERR_UNSUPPORTED); the traversal arrays of the bound scene must be current, i.e.
  * pt_pass_intersect or pt_pass_draw ran since the scene buffers last changed (PT_ERR_STATE
- * otherwise: laying them out allocates).  All calls on one GPU share that GPU's array:
- * calls that overlap on one GPU (two contexts, two host threads) race. */
+ * otherwise: laying them out allocates).  All calls on one GPU share that GPU's array: a call
+ * queues itself behind the previous call's launches when those went to another context's stream
+ * (an event made when the first context of the device was created; no allocation), so calls from
+ * several contexts or host threads on one GPU take turns; they do not run side by side. */
 int pt_pass_intersect_noalloc(pt_pass *pass, const pt_buf *rays, size_t n, pt_buf *hits);
 
 /* ---- multi-GPU: sample slicing over RCCL ------------------------------------------------

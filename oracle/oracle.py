@@ -291,6 +291,32 @@ def ref_intersect(scene_data, rays):
     return np.frombuffer(raw, np.dtype([("instance", "<i4"), ("triangle", "<i4"), ("t", "<f4")]), len(rays)).copy()
 
 
+def ref_intersect_scene(scene_data, nodes, rays):
+    """The reference's CPU picking path run as the application runs it (main.cpp:125-146): real Instance / Transform
+    objects in a hierarchy, the scene BVH of ResourceManager::reload_scene over them, BVHNode::rayIntersect entered at
+    the SCENE root (src/BVH.cpp:89-114, scene-leaf branch included).  scene_data supplies the meshes (tri_count,
+    triangles); nodes: list of (position, rotation_deg, scale, mesh or -1, parent or -1) with parents before children.
+    Returns (hits, l2w (n_inst, 16), mesh_index (n_inst,)): the instances are the nodes with a mesh in pre-order and
+    l2w the matrices the reference's hierarchy walk accumulated for them."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    with tempfile.TemporaryDirectory() as d:
+        _write_meshes(d + "/m.bin", scene_data)
+        with open(d + "/n.bin", "wb") as f:
+            f.write(struct.pack("<i", len(nodes)))
+            for pos, rot, scl, mesh, parent in nodes:
+                f.write(np.asarray(list(pos) + list(rot) + list(scl), np.float32).tobytes())
+                f.write(struct.pack("<2i", int(mesh), int(parent)))
+        with open(d + "/r.bin", "wb") as f:
+            f.write(struct.pack("<i", len(rays)))
+            f.write(rays.tobytes())
+        subprocess.check_call([REF_HARNESS, "isect_scene", d + "/m.bin", d + "/n.bin", d + "/r.bin", d + "/o.bin"])
+        raw = open(d + "/o.bin", "rb").read()
+    n_inst, = struct.unpack_from("<i", raw, 0)
+    hits = np.frombuffer(raw, np.dtype([("instance", "<i4"), ("triangle", "<i4"), ("t", "<f4")]), len(rays), 4).copy()
+    rec = np.frombuffer(raw, np.dtype([("l2w", "<f4", 16), ("mesh", "<i4")]), n_inst, 4 + 12 * len(rays))
+    return hits, rec["l2w"].copy(), rec["mesh"].copy()
+
+
 def ref_scene_level(scene_data):
     """The reference's scene level for the instances of scene_data (ResourceManager::reload_scene,
     reload_sceneBVH, reload_instances run over its own AABB / glm / BVHNode::build): returns

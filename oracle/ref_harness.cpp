@@ -121,13 +121,12 @@ static int cmd_bvh(const char *in, const char *out) {
     return 0;
 }
 
-// CPU picking path: BVHNode::rayIntersect (src/BVH.cpp:89-114) at mesh level.
-// The instance leaf of the reference does  w2l = inverse(matrix_to_global());
-// ray.ori = w2l*vec4(ori,1); ray.dir = w2l*vec4(dir,0)  (BVH.cpp:91-93) and descends;
-// Instance/Transform cannot be linked headless, so the same three statements are
-// executed here with the l2w matrix read from the scene file, for every instance in
-// turn (the scene-level tree only culls; it never changes which triangle is closest
-// except through t ties).
+// CPU picking path at mesh level: BVHNode::rayIntersect (src/BVH.cpp:97-114) entered at every mesh root in
+// turn, with the three statements of its scene-leaf branch (BVH.cpp:91-93: w2l = inverse(l2w), ray.ori =
+// w2l * vec4(ori, 1), ray.dir = w2l * vec4(dir, 0)) executed here on a matrix read from the scene file.
+// This form takes ANY local-to-world matrix (sheared, singular ...); cmd_isect_scene below runs the whole
+// routine from the scene root, scene-leaf branch included, for instances whose matrices come from the
+// reference's own Transform / Instance objects.
 static int cmd_isect(const char *meshes, const char *scene, const char *rays, const char *out) {
     MeshSet ms; load_meshes(meshes, ms);
     std::map<Triangle*, int> triIndex;
@@ -165,6 +164,106 @@ static int cmd_isect(const char *meshes, const char *scene, const char *rays, co
         // global index of the triangle inside the mesh array, as the flat buffers do
         float t = isect.t;
         fwrite(&hitInst, 4, 1, f); fwrite(&tri, 4, 1, f); fwrite(&t, 4, 1, f);
+    }
+    fclose(f);
+    return 0;
+}
+
+// The CPU picking path as the reference runs it (mouse_clickcalback, main.cpp:125-146): a hierarchy of real
+// Instance objects with real Transforms (src/instance/Instance.cpp, src/Transform.cpp, compiled in
+// ref_transform_unit.cpp), the scene BVH made by the statements of ResourceManager::reload_scene /
+// update_globalinstance_recursive (src/ResourceManager.cpp:47-77, 200-221) over BVHNode::build, and
+// BVHNode::rayIntersect (src/BVH.cpp:89-114) entered at the SCENE root: its scene-leaf branch
+// (inverse(instancePtr->matrix_to_global()), the descent into the mesh tree) runs as written.  A Mesh cannot be
+// constructed headless (its constructor creates GL objects): rayIntersect and build read meshBVHRoot only, so
+// a Mesh is zeroed storage of the reference's class layout with that member set.
+//   nodes file : i32 nnodes ; per node { f32 position[3], rotation_deg[3], scale[3] ; i32 mesh (-1: none) ;
+//                i32 parent (-1: child of the scene root, else the index of an EARLIER node) }
+//                instances = the nodes that carry a mesh, in hierarchy pre-order (children in file order)
+//   out        : i32 ninst ; per ray { i32 inst ; i32 tri (global) ; f32 t } ;
+//                per instance { f32 transform2world[16] ; i32 mesh }   (the matrix reload_instances inverts)
+static int cmd_isect_scene(const char *meshes, const char *nodes_path, const char *rays, const char *out) {
+    MeshSet ms; load_meshes(meshes, ms);
+    std::map<Triangle*, int> triIndex;
+    for(size_t m = 0; m < ms.tris.size(); m++)
+        for(size_t i = 0; i < ms.tris[m].size(); i++) triIndex[&ms.tris[m][i]] = ms.triBase[m] + (int)i;
+    std::vector<char> nb = slurp(nodes_path);
+    const char *p = nb.data();
+    int nnodes; memcpy(&nnodes, p, 4); p += 4;
+    Instance *scene = new Instance("scene");
+    std::vector<Instance*> node(nnodes);
+    std::map<Mesh*, int> meshIndexOf;
+    for(int k = 0; k < nnodes; k++) {
+        float prs[9]; int mesh, parent;
+        memcpy(prs, p, 36); p += 36;
+        memcpy(&mesh, p, 4); p += 4;
+        memcpy(&parent, p, 4); p += 4;
+        if(parent >= k || mesh >= (int)ms.roots.size()) { fprintf(stderr, "bad nodes file\n"); return 2; }
+        Instance *ins = new Instance("node");
+        ins->transform = Transform(vec3(prs[0], prs[1], prs[2]), vec3(prs[3], prs[4], prs[5]), vec3(prs[6], prs[7], prs[8]));
+        if(mesh >= 0) {
+            Mesh *m = static_cast<Mesh*>(calloc(1, sizeof(Mesh)));
+            m->meshBVHRoot = ms.roots[mesh];
+            meshIndexOf[m] = mesh;
+            ins->mesh = m;
+        }
+        (parent < 0 ? scene : node[parent])->add_child(ins);
+        node[k] = ins;
+    }
+    // ResourceManager::update_globalinstance_recursive, src/ResourceManager.cpp:58-77 (without the lights)
+    std::vector<std::pair<Instance*, mat4>> globalInstances;
+    std::map<Instance*, int> instanceIndexMap;
+    struct Walk {
+        std::vector<std::pair<Instance*, mat4>> &gi;
+        std::map<Instance*, int> &im;
+        void run(Instance *cur, mat4 transform2world) {
+            if(cur->mesh) {
+                im[cur] = (int)gi.size();
+                gi.emplace_back(cur, transform2world);
+            }
+            Instance *child;
+            for(int i = 0; (child = cur->get_child(i)) != nullptr; i++) run(child, transform2world * child->transform.matrix());
+        }
+    } walk{globalInstances, instanceIndexMap};
+    walk.run(scene, mat4(1.0));
+    // ResourceManager::reload_scene, src/ResourceManager.cpp:203-220
+    std::vector<BVHPrimitive> primitives;
+    for(auto &[u, mat]: globalInstances) {
+        BVHPrimitive prim;
+        prim.instancePtr = u;
+        AABB cube = u->mesh->meshBVHRoot->aabb;
+        for(int i = 0;i < 8;i++) {
+            vec3 point = {
+                    (i & 1) ? cube.mi[0] : cube.mx[0],
+                    (i & 2) ? cube.mi[1] : cube.mx[1],
+                    (i & 4) ? cube.mi[2] : cube.mx[2]
+            };
+            point = mat * vec4(point, 1);
+            prim.aabb.addPoint(point);
+        }
+        primitives.push_back(prim);
+    }
+    BVHNode *root = BVHNode::build(primitives);   // reference code
+    std::vector<char> rb = slurp(rays);
+    int nrays; memcpy(&nrays, rb.data(), 4);
+    const float *r = (const float*)(rb.data() + 4);
+    FILE *f = fopen(out, "wb");
+    int ninst = (int)globalInstances.size();
+    fwrite(&ninst, 4, 1, f);
+    for(int k = 0; k < nrays; k++) {
+        vec3 ori(r[k*6], r[k*6+1], r[k*6+2]), dir(r[k*6+3], r[k*6+4], r[k*6+5]);
+        Ray ray(ori, dir);
+        Intersection isect;
+        root->rayIntersect(ray, isect, nullptr);   // reference code, from the scene root (main.cpp:135-137)
+        int inst = isect.exist ? instanceIndexMap[isect.instancePtr] : -1;
+        int tri = isect.exist ? triIndex[isect.trianglePtr] : -1;
+        float t = isect.t;
+        fwrite(&inst, 4, 1, f); fwrite(&tri, 4, 1, f); fwrite(&t, 4, 1, f);
+    }
+    for(auto &[u, mat]: globalInstances) {
+        fwrite(&mat[0][0], 4, 16, f);
+        int mi = meshIndexOf[u->mesh];
+        fwrite(&mi, 4, 1, f);
     }
     fclose(f);
     return 0;
@@ -331,10 +430,12 @@ int main(int argc, char **argv) {
     if(c == "bvh" && argc == 4) return cmd_bvh(argv[2], argv[3]);
     if(c == "isect" && argc == 6) return cmd_isect(argv[2], argv[3], argv[4], argv[5]);
     if(c == "scene" && argc == 5) return cmd_scene(argv[2], argv[3], argv[4]);
+    if(c == "isect_scene" && argc == 6) return cmd_isect_scene(argv[2], argv[3], argv[4], argv[5]);
     if(c == "mat" && argc == 4) return cmd_mat(argv[2], argv[3]);
     if(c == "hdr" && argc == 3) return cmd_hdr(argv[2]);
     if(c == "stb" && argc == 4) return cmd_stb(argv[2], argv[3]);
-    fprintf(stderr, "usage: ref_harness bvh <meshes> <out> | isect <meshes> <scene> <rays> <out> | scene <meshes> <scene> <out> | "
+    fprintf(stderr, "usage: ref_harness bvh <meshes> <out> | isect <meshes> <scene> <rays> <out> | isect_scene <meshes> <nodes> <rays> <out> | "
+                    "scene <meshes> <scene> <out> | "
                     "mat <in> <out> | hdr <out> | stb <image> <out>\n");
     return 2;
 }

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -71,6 +72,13 @@ constexpr size_t NOALLOC_SCRATCH_BYTES =
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 constexpr int NOALLOC_MAX_DEVICES = 64;
 static void *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+// Every context on a GPU shares that GPU's array, and every context has a stream of its own: a call orders itself
+// behind the last call that used the array (an event recorded after its launches, made once per device in
+// pt_ctx_create; waiting on it allocates nothing), so calls from several contexts or host threads take turns
+// instead of corrupting each other's counters and spill entries.
+static std::mutex g_scratch_mutex;
+static hipEvent_t g_scratch_event[NOALLOC_MAX_DEVICES] = {};
+static hipStream_t g_scratch_last_stream[NOALLOC_MAX_DEVICES] = {};
 
 struct pt_pass {
     pt_ctx *ctx = nullptr;
@@ -684,11 +692,15 @@ int pt_ctx_create(int device_id, pt_ctx **out) {
         return fail(PT_ERR_UNSUPPORTED, std::string("pt_ctx_create: this library is built for gfx950 only, device is ") + prop.gcnArchName);
     // each GPU holds its own copy of the scratch array at its own address: ask once per device, with it current
     if(device_id >= NOALLOC_MAX_DEVICES) return fail(PT_ERR_UNSUPPORTED, "pt_ctx_create: device index beyond " + std::to_string(NOALLOC_MAX_DEVICES - 1));
-    if(!g_scratch_ptr[device_id]) {
-        void *sp = nullptr;
-        HIP_TRY(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
-        if(!sp) return fail(PT_ERR_HIP, "pt_ctx_create: hipGetSymbolAddress returned no address for the scratch array");
-        g_scratch_ptr[device_id] = sp;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if(!g_scratch_ptr[device_id]) {
+            void *sp = nullptr;
+            HIP_TRY(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+            if(!sp) return fail(PT_ERR_HIP, "pt_ctx_create: hipGetSymbolAddress returned no address for the scratch array");
+            HIP_TRY(hipEventCreateWithFlags(&g_scratch_event[device_id], hipEventDisableTiming));
+            g_scratch_ptr[device_id] = sp;
+        }
     }
     pt_ctx *c = new pt_ctx;
     c->device = device_id;
@@ -1487,6 +1499,10 @@ int pt_pass_intersect_noalloc(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *
     unsigned *redo = reinterpret_cast<unsigned *>(base + NOALLOC_REDO_OFFSET);
     void *spill = base + NOALLOC_SPILL_OFFSET;
     hipStream_t s = ctx->stream;
+    // one user of this GPU's array at a time: behind the last call's launches when they went to another stream
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if(g_scratch_last_stream[ctx->device] && g_scratch_last_stream[ctx->device] != s)
+        HIP_TRY(hipStreamWaitEvent(s, g_scratch_event[ctx->device], 0));
     // the array keeps the last call's contents: the counters must start at zero
     HIP_TRY(hipMemsetAsync(cnt, 0, NOALLOC_REDO_OFFSET, s));
     long long blocks = ((long long)n + TRACE_BLOCK - 1) / TRACE_BLOCK;
@@ -1502,6 +1518,8 @@ int pt_pass_intersect_noalloc(pt_pass *p, const pt_buf *rays, size_t n, pt_buf *
         launch_intersect(s, sc, (int)blocks, static_cast<const float *>(rays->dptr), (unsigned)n, nullptr, nullptr,
                          static_cast<pt_hit *>(hits->dptr), cnt, nullptr);
     }
+    HIP_TRY(hipEventRecord(g_scratch_event[ctx->device], s));
+    g_scratch_last_stream[ctx->device] = s;
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }

@@ -111,6 +111,27 @@ def test_hip_closest_hits_equal_the_compiled_reference_ray_caster(gpu_ctx, casa,
     assert rel.max() <= 1e-5
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_hip_closest_hits_equal_the_reference_ray_caster_entered_at_the_scene_root(gpu_ctx, mode):
+    """tests/golden/scene_rays.npz: nested groups of mirrored / unevenly scaled / rotated / overlapping instances, the
+    reference's routine run from the scene root over its own Instance and Transform objects."""
+    from raytracing_amd import device
+    from test_oracle import scene_of_fixture
+    k = np.load(os.path.join(GOLDEN, "scene_rays.npz"))
+    sd = scene_of_fixture(k)
+    sb = device.SceneBuffers(gpu_ctx, sd)
+    p = device.PathTracingPass(gpu_ctx, 16, 16)
+    p.bind_scene(sb)
+    p.set_traversal(mode)
+    hits = device.trace_rays(p, k["rays"])
+    if mode == 3:
+        assert p.stats()["flat_leaves"] > 0          # (rotated instances: the flattened tree only when asked for)
+    p.destroy()
+    sb.release()
+    from test_oracle import assert_same_hits_up_to_edge_rays
+    assert_same_hits_up_to_edge_rays(hits, k)
+
+
 def test_mesh_bvh_of_the_library_equals_the_reference_build():
     """pt_host_build_mesh_bvh through the C ABI on the demo scene, hashed against the node array the
     reference's compiled builder produced (run on the GPU box too, so that the driver's record shows it)."""
@@ -141,3 +162,4 @@ def test_oracle_bsdfs_equal_the_reference_glsl(oracle_mod):
 def test_oracle_closest_hits_equal_the_compiled_reference_ray_caster(casa, oracle_mod):
     import test_oracle
     test_oracle.test_closest_hit_equals_reference_picking(casa, oracle_mod)
+    test_oracle.test_closest_hit_equals_reference_picking_from_the_scene_root(oracle_mod)

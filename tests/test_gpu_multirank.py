@@ -33,17 +33,18 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     # (no launcher: bench.py --gpus 2 starts its two ranks itself)
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", *common, "--dump", two],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--scaling", "weak", *common, "--dump", two],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     import json
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
-    # strong scaling: the same 6 samples, now as --steps 6 cut over the two ranks
+    assert out["allreduce_ms"] > 0 and len(out["per_rank"]) == 2 and all(r["samples"] == 3 and r["draw_ms"] > 0 for r in out["per_rank"])
+    # strong scaling (the default with more than one rank): the same 6 samples, now as --steps 6 cut over the two ranks
     three = str(tmp_path / "three.npz")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--scaling", "strong",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse",
                         *common[:1], "6", *common[2:], "--dump", three], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     out3 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -70,8 +71,15 @@ def test_capi_allreduce_world_of_one(gpu_ctx, casa, small_sky):
     """pt_comm_* / pt_pass_allreduce over RCCL with the one GPU of the test box as a world of one
     rank: sums of 4 samples / 4 must equal the running mean of the same samples up to fp32
     summation order, and the last-write outputs are untouched.  (More than one rank per GPU is
-    refused by RCCL, so N > 1 runs only where there are N GPUs: bench.py --gpus N.)"""
-    from raytracing_amd import device, multigpu, scene
+    refused by RCCL, so N > 1 runs only where there are N GPUs: bench.py --gpus N.  That leg --
+    pt_comm_create with world > 1, pt_comm_create_all, pt_pass_allreduce_all -- has not run on hardware from this test.)"""
+    from raytracing_amd import _capi, device, multigpu, scene
+    try:
+        uid = device.Comm.unique_id()
+    except _capi.PtError as e:
+        if "librccl" in str(e) or "RCCL" in str(e):
+            pytest.skip("RCCL is not installed on this box: %s" % e)
+        raise
     w, h, spp = 256, 144, 4
     sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
     p = device.PathTracingPass(gpu_ctx, w, h)
@@ -89,7 +97,7 @@ def test_capi_allreduce_world_of_one(gpu_ctx, casa, small_sky):
     for name in multigpu.ACCUMULATED:
         p.outputs[name].fill(0.0)
     frame(1)
-    comm = device.Comm(gpu_ctx, device.Comm.unique_id(), 0, 1)
+    comm = device.Comm(gpu_ctx, uid, 0, 1)
     multigpu.allreduce_outputs_capi(comm, p, spp)        # queued behind the draws, no wait in between
     got = p.download()
     for name in multigpu.LAST_WRITE:
@@ -98,7 +106,6 @@ def test_capi_allreduce_world_of_one(gpu_ctx, casa, small_sky):
         x, y = mean[name].astype(np.float64), got[name].astype(np.float64)
         err = np.abs(x - y) / np.maximum(np.maximum(np.abs(x), np.abs(y)), 1e-3)
         assert np.all((err < 1e-5) | (np.isnan(x) & np.isnan(y))), (name, float(np.nanmax(err)))
-    from raytracing_amd import _capi
     with pytest.raises(_capi.PtError):
         comm.allreduce(p, 0, 0)
     with pytest.raises(_capi.PtError):

@@ -68,3 +68,33 @@ def test_noalloc_matches_intersect_twice(casa, gpu_ctx):
         b.release()
     p.destroy()
     sb.release()
+
+
+def test_two_contexts_on_one_gpu_take_turns(casa, gpu_ctx):
+    """Every context on a GPU shares that GPU's scratch array and has a stream of its own: calls issued back to back
+    from two contexts, with no wait in between, must not touch each other's counters, redo list or spill entries."""
+    from raytracing_amd import device
+    lo, hi = casa.world_box()
+    ctx2 = device.Context(0)
+    state = []
+    for ctx, n, seed in ((gpu_ctx, 1 << 20, 303), (ctx2, 200_000, 404)):
+        sb = device.SceneBuffers(ctx, casa)
+        p = device.PathTracingPass(ctx, 16, 16)
+        p.bind_scene(sb)
+        rb = device.Buffer(ctx, random_rays(lo, hi, n, seed))
+        ref_b = device.Buffer(ctx, nbytes=n * device.HIT_DTYPE.itemsize)
+        new_b = device.Buffer(ctx, nbytes=n * device.HIT_DTYPE.itemsize)
+        p.intersect(rb, n, ref_b)
+        ref = ref_b.download(np.uint8).view(device.HIT_DTYPE).copy()
+        state.append((sb, p, rb, ref_b, new_b, n, ref))
+    for rep in range(3):
+        for sb, p, rb, ref_b, new_b, n, ref in state:     # queued on two streams, nobody waits
+            p.intersect_noalloc(rb, n, new_b)
+        for sb, p, rb, ref_b, new_b, n, ref in state:
+            _same(new_b.download(np.uint8).view(device.HIT_DTYPE)[:n], ref)
+    for sb, p, rb, ref_b, new_b, n, ref in state:
+        for b in (rb, ref_b, new_b):
+            b.release()
+        p.destroy()
+        sb.release()
+    ctx2.destroy()
