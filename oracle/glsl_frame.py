@@ -85,8 +85,9 @@ def tex_blob(a, nearest=False):
     return pad16(struct.pack("<5i", w, h, c, int(a.dtype == np.float32), int(nearest))) + pad16(a.tobytes())
 
 
-def run(exe, sd, sky, prm, jitters, gbuf, workdir):
-    """gbuf: per sample (depth, normal, uv, instance) float images h x w x c, row 0 = bottom row."""
+def run(exe, sd, sky, prm, jitters, gbuf, workdir, processes=1):
+    """gbuf: per sample (depth, normal, uv, instance) float images h x w x c, row 0 = bottom row.
+    processes > 1: the rows are cut into that many bands, one process of the harness each."""
     u = struct.pack("<5i", prm.SCREEN_W, prm.SCREEN_H, prm.WINDOW_W, prm.WINDOW_H, prm.MAX_DEPTH)
     u += struct.pack("<4f", prm.fov, prm.cameraNear, prm.cameraFar, prm.skybox_Light_SUM)
     u += struct.pack("<2i", prm.SKY_W, prm.SKY_H)
@@ -111,17 +112,24 @@ def run(exe, sd, sky, prm, jitters, gbuf, workdir):
         blob += tex_blob(g[0]) + tex_blob(g[1]) + tex_blob(g[2]) + tex_blob(g[3], nearest=True)
     fin, fout = os.path.join(workdir, "glsl_frame_in.bin"), os.path.join(workdir, "glsl_frame_out.bin")
     open(fin, "wb").write(blob)
-    r = subprocess.run([exe, fin, fout], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("glsl_frame_harness failed (%d): %s" % (r.returncode, r.stderr[-2000:]))
-    raw = np.fromfile(fout, np.float32)
     w, h = prm.SCREEN_W, prm.SCREEN_H
-    out, off = {}, 0
-    for name, c in (("albedo", 3), ("motion", 2), ("depth", 1), ("normal", 3), ("instanceIndex", 1), ("directLum", 3), ("indirectLum", 3)):
-        out[name] = raw[off:off + w * h * c].reshape(h, w, c).copy()
-        off += w * h * c
+    bands = [(h * k // processes, h * (k + 1) // processes) for k in range(processes)]
+    procs = [subprocess.Popen([exe, fin, "%s.%d" % (fout, k), str(y0), str(y1)], stderr=subprocess.PIPE, text=True)
+             for k, (y0, y1) in enumerate(bands)]
+    out = {}
+    for k, (pr, (y0, y1)) in enumerate(zip(procs, bands)):
+        err = pr.communicate()[1]
+        if pr.returncode != 0:
+            raise RuntimeError("glsl_frame_harness failed (%d): %s" % (pr.returncode, err[-2000:]))
+        raw = np.fromfile("%s.%d" % (fout, k), np.float32)
+        off = 0
+        for name, c in (("albedo", 3), ("motion", 2), ("depth", 1), ("normal", 3), ("instanceIndex", 1), ("directLum", 3), ("indirectLum", 3)):
+            if name not in out:
+                out[name] = np.zeros((h, w, c), np.float32)
+            out[name][y0:y1] = raw[off:off + w * h * c].reshape(h, w, c)[y0:y1]
+            off += w * h * c
+        os.remove("%s.%d" % (fout, k))
     os.remove(fin)
-    os.remove(fout)
     return out
 
 

@@ -183,6 +183,10 @@ int main(int argc, char **argv) {
     albedoGBuffer = o_albedo.data(); motionGBuffer = o_motion.data(); depthGBuffer = o_depth.data(); normalGBuffer = o_normal.data();
     instanceIndexGBuffer = o_inst.data(); directLumGBuffer = o_di.data(); indirectLumGBuffer = o_idi.data();
 
+    // optional row band [y_begin, y_end): a large frame is cut over several PROCESSES (the shader keeps state in globals --
+    // its traversal stack, the sampler -- so threads would not do); rows outside the band stay zero in the output
+    const int y_begin = argc > 4 ? atoi(argv[3]) : 0, y_end = argc > 4 ? atoi(argv[4]) : SCREEN_H;
+    if(y_begin < 0 || y_end > SCREEN_H || y_begin > y_end) return 2;
     // the frame loop of main.cpp:169-208: one full-screen pass per spp, one fragment per pixel, fragment
     // coordinates at pixel centres (what the rasteriser gives a full-screen quad)
     for(uint32_t spp = 1; spp <= n_spp; spp++) {
@@ -192,7 +196,7 @@ int main(int argc, char **argv) {
         normalGBufferTexture = gbuf[4 * (spp - 1) + 1];
         uvGBufferTexture = gbuf[4 * (spp - 1) + 2];
         instanceIndexGBufferTexture = gbuf[4 * (spp - 1) + 3];
-        for(int y = 0; y < SCREEN_H; y++)
+        for(int y = y_begin; y < y_end; y++)
             for(int x = 0; x < SCREEN_W; x++) {
                 screen_uv = vec2(((float)x + 0.5f) / (float)SCREEN_W, ((float)y + 0.5f) / (float)SCREEN_H);
                 stack_h = 0;

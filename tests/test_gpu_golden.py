@@ -163,3 +163,65 @@ def test_oracle_closest_hits_equal_the_compiled_reference_ray_caster(casa, oracl
     import test_oracle
     test_oracle.test_closest_hit_equals_reference_picking(casa, oracle_mod)
     test_oracle.test_closest_hit_equals_reference_picking_from_the_scene_root(oracle_mod)
+
+
+def test_hip_pass_golden_configuration_at_1280x720(gpu_ctx, casa):
+    """The golden configuration at its stated size (demo scene, 1280x720, 1 spp, MaxDepth 2, main.cpp:376-388,
+    Config.h:58-72): every byte of the seven outputs must hash to what the reference's shader text produced
+    (tests/golden/glsl_config1.npz, oracle/glsl_config1.py).  The raster pass's depth and instance-index images, which the
+    shader reads even when it traces the first hit (pathtracing.glsl:615-616), hold the primary hits: made here by a
+    MAX_DEPTH 0 draw of the pass itself."""
+    from raytracing_amd import device, scene
+    from test_oracle import CONFIG1, check_config1_frame
+    w, h, depth = CONFIG1
+    k = np.load(os.path.join(GOLDEN, "glsl_config1.npz"))
+    sky = scene.procedural_sky(2048, 1024)
+    sb = device.SceneBuffers(gpu_ctx, casa, sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    p.set_params(scene.make_params(w, h, scene.casa_camera(), sky, spp=1, frame=1, max_depth=0))
+    p.draw()
+    prim = p.download()
+    td = device.Texture(gpu_ctx, np.ascontiguousarray(prim["depth"].reshape(h, w, 1)))
+    ti = device.Texture(gpu_ctx, np.ascontiguousarray(prim["instanceIndex"].reshape(h, w, 1)))
+    p.bind_texture("depthGBufferTexture", td)
+    p.bind_texture("instanceIndexGBufferTexture", ti)
+    p.set_params(scene.make_params(w, h, scene.casa_camera(), sky, spp=1, frame=1, jitter=(0.5, 0.5), max_depth=depth))
+    p.draw()
+    got = p.download()
+    st = p.stats()
+    p.destroy()
+    td.release(); ti.release()
+    sb.release()
+    assert st["reference_order_forced"] == 0
+    check_config1_frame(got, k, "HIP")
+
+
+def test_hip_high_spp_frame_matches_the_reference_shader_within_monte_carlo_noise(gpu_ctx, casa, small_sky):
+    """tests/golden/glsl_spp16.npz: 16 spp of the reference's shader run with another maths library; the HIP pass's 16-spp
+    frame (drawn as ONE batch) must lie within a small fraction of the Monte Carlo standard error of it."""
+    from raytracing_amd import device, scene
+    from test_oracle import SPP16, check_high_spp_frame
+    w, h, depth, spp = SPP16
+    k = np.load(os.path.join(GOLDEN, "glsl_spp16.npz"))
+    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    jit = scene.mt19937_jitters(spp)
+    p.draw_batch([scene.make_params(w, h, scene.casa_camera(), small_sky, spp=s, frame=1, jitter=jit[s - 1], max_depth=depth)
+                  for s in range(1, spp + 1)])
+    mean16 = p.download()
+    singles = []
+    for s in range(1, spp + 1):
+        p.set_params(scene.make_params(w, h, scene.casa_camera(), small_sky, spp=1, frame=s, jitter=jit[s - 1], max_depth=depth))
+        p.draw()
+        singles.append(p.download())
+    p.destroy()
+    sb.release()
+    check_high_spp_frame(mean16, singles, k, "HIP")
+
+
+def test_oracle_golden_configuration_and_high_spp_frame(casa, small_sky, oracle_mod):
+    import test_oracle
+    test_oracle.test_golden_configuration_at_1280x720_equals_the_reference_shader(casa, oracle_mod)
+    test_oracle.test_high_spp_frame_matches_the_reference_shader_within_monte_carlo_noise(casa, small_sky, oracle_mod)
