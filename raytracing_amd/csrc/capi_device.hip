@@ -857,7 +857,9 @@ int pt_tex_create(pt_ctx *ctx, int width, int height, int channels, int format, 
     pt_tex *t = new pt_tex;
     t->ctx = ctx;
     t->width = width; t->height = height; t->channels = channels; t->format = format;
-    hipError_t e = hipMalloc(&t->dptr, bytes);
+    // (16 bytes behind the last texel: the kernels read a three-byte texel as one word)
+    hipError_t e = hipMalloc(&t->dptr, bytes + 16);
+    if(e == hipSuccess) e = hipMemsetAsync(static_cast<char *>(t->dptr) + bytes, 0, 16, ctx->stream);
     if(e == hipSuccess) e = hipMemcpyAsync(t->dptr, data, bytes, hipMemcpyHostToDevice, ctx->stream);
     if(e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if(e != hipSuccess) {

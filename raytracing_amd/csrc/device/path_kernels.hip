@@ -26,6 +26,10 @@ constexpr int SHADE_BLOCK = RT_SHADE_BLOCK;
 #define RT_SHADE_GROUP_BLOCK 256
 #endif
 constexpr int SHADE_GROUP_BLOCK = RT_SHADE_GROUP_BLOCK;
+#ifndef RT_SHADE_ROUND
+#define RT_SHADE_ROUND 8
+#endif
+constexpr int SHADE_ROUND = RT_SHADE_ROUND;  // batches of 64 paths a wave shades between two updates of the queue counters
 
 __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
     const unsigned nthreads = gridDim.x * blockDim.x;
@@ -40,16 +44,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
             o = v3(0.0f);
             d = v3(__uint_as_float(0x7FC00000u));
         }
+        // (the rays only: the launch that shades vertex 0 knows what throughput, sampler dimension and accumulators
+        // start with, shade_vertex.h)
         float4 *r = reinterpret_cast<float4 *>(dp.rays + i);
         r[0] = make_float4(o.x, o.y, o.z, 0.0f);
         r[1] = make_float4(d.x, d.y, d.z, 0.0f);
-        float4 *t = reinterpret_cast<float4 *>(dp.thr + i);
-        t[0] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        t[1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(1u));  // sobolcurdim = 1, :602
-        float4 *a = reinterpret_cast<float4 *>(dp.acc + i);
-        a[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        a[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        a[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if(blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch);
@@ -68,7 +67,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void generate_kernel(DrawParams dp) {
 // GROUP: every block first sorts its paths into two groups, so that a wave mostly holds one kind (below); such
 // launches use blocks of SHADE_GROUP_BLOCK threads (four waves to sort among; measured on the demo scene, shade
 // time per draw: 0.93 ms ungrouped, 0.85 / 0.82 / 0.88 ms with blocks of 128 / 256 / 512).
-template <int RASTER, bool GROUP>
+// FIRST: the launch of vertex 0 (dep == 0), see shade_vertex
+template <int RASTER, bool GROUP, bool FIRST>
 __global__ __launch_bounds__(GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES, SHADE_WAVES))) void shade_kernel(DrawParams dp, int dep, const unsigned *queue_in,
                                                             const unsigned *count_in, unsigned *queue_out,
                                                             unsigned *count_out, unsigned *shadow_queue,
@@ -77,68 +77,108 @@ __global__ __launch_bounds__(GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK) __attribut
     __shared__ __align__(16) unsigned s_V[SOBOL_NIBBLE_WORDS];
     __shared__ unsigned s_null;  // light samples of this block that needed no occlusion query
     const unsigned n = *count_in;
-    if(blockIdx.x * blockDim.x >= n && blockIdx.x != 0) return;  // (late bounces fill few blocks; block 0 books the counters)
+    const unsigned nthreads = gridDim.x * blockDim.x;
+    {
+        // (late bounces fill few blocks; block 0 books the counters)
+        const unsigned per_thread0 = (n + nthreads - 1u) / nthreads;
+        const unsigned U0 = per_thread0 < 1u ? 1u : (per_thread0 > (unsigned)SHADE_ROUND ? (unsigned)SHADE_ROUND : per_thread0);
+        if(blockIdx.x * blockDim.x * U0 >= n && blockIdx.x != 0) return;
+    }
     if(threadIdx.x == 0) s_null = 0u;
     unsigned my_null = 0u;
     load_sobol_to_lds(s_V);
-    const unsigned nthreads = gridDim.x * blockDim.x;
 
     if(blockIdx.x == 0 && threadIdx.x == 0) {
         // (with RasterizaionFor1st the first vertex comes from images: no rays were traced for it)
-        if(RASTER != 1) atomicAdd(&dp.stats[1], dep == 0 ? (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch : (unsigned long long)n);
+        if(RASTER != 1) atomicAdd(&dp.stats[1], FIRST ? (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch : (unsigned long long)n);
         if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
     }
 
     __shared__ unsigned s_slot[GROUP ? BLOCK : 1];
     __shared__ unsigned s_count[GROUP ? BLOCK / 64 : 1];
-    for(unsigned q0 = blockIdx.x * blockDim.x; q0 < n; q0 += nthreads) {
-        const unsigned q = q0 + threadIdx.x;
-        unsigned i = q < n ? (queue_in ? queue_in[q] : q) : 0u;
-        bool mine = q < n;
-        if(GROUP) {
-            // One group goes to the back of the block's paths, the other stays in front, order kept
-            // within each group; which lane shades a path changes nothing about what is computed for it.
-            bool back = false;
-            if(mine) {
-                const int inst = RASTER == 1 ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[1].x);
-                const int tri = RASTER == 1 ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[0].w);
-                // escaped paths (a sky lookup, then done) behind the ones that hit something (the long branch); among
-                // those, when asked for, dielectrics behind conductors
-                back = tri < 0;
-                if(group_materials && tri >= 0 && inst >= 0 && inst < dp.n_instances) back = dp.inst[inst].material_type == 2u;
+    // Queue appends.  Every counter update is an atomic on ONE word, and the chip completes about ninety of those per
+    // microsecond whoever issues them: with one update per wave and 64 paths a launch over 33 M paths (sixteen samples
+    // of a 1080p frame) spent 5.9 ms waiting for its half a million updates and 3.3 ms without them.  So a wave shades
+    // up to SHADE_ROUND batches of 64 paths, keeps what they append in LDS (one word per thread and batch, read back by
+    // the thread that wrote it), and then makes ONE update per queue for all of them.  A launch with fewer paths than
+    // threads runs one batch per round, as before: thin launches want every block busy.
+    __shared__ unsigned s_stage[SHADE_ROUND * BLOCK];
+    const unsigned per_thread = (n + nthreads - 1u) / nthreads;
+    const unsigned U = per_thread < 1u ? 1u : (per_thread > (unsigned)SHADE_ROUND ? (unsigned)SHADE_ROUND : per_thread);
+    const unsigned lane = threadIdx.x & 63u;
+    for(unsigned r0 = blockIdx.x * blockDim.x * U; r0 < n; r0 += nthreads * U) {
+        unsigned cont_bits = 0u, shad_bits = 0u;
+#pragma unroll 1
+        for(unsigned u = 0; u < U; u++) {
+            const unsigned q0 = r0 + u * blockDim.x;
+            if(q0 >= n) break;  // (the same for every thread of the block)
+            const unsigned q = q0 + threadIdx.x;
+            unsigned i = q < n ? (queue_in ? queue_in[q] : q) : 0u;
+            bool mine = q < n;
+            if(GROUP) {
+                // One group goes to the back of the block's paths, the other stays in front, order kept
+                // within each group; which lane shades a path changes nothing about what is computed for it.
+                bool back = false;
+                if(mine) {
+                    const int inst = RASTER == 1 ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[1].x);
+                    const int tri = RASTER == 1 ? -1 : __float_as_int(reinterpret_cast<const float4 *>(dp.hits + i)[0].w);
+                    // escaped paths (a sky lookup, then done) behind the ones that hit something (the long branch); among
+                    // those, when asked for, dielectrics behind conductors
+                    back = tri < 0;
+                    if(group_materials && tri >= 0 && inst >= 0 && inst < dp.n_instances) back = dp.inst[inst].material_type == 2u;
+                }
+                const unsigned wave = threadIdx.x >> 6;
+                const unsigned long long m_back = __ballot(back), m_front = __ballot(mine && !back);
+                if(lane == 0u) s_count[wave] = (unsigned)__popcll(m_front) | ((unsigned)__popcll(m_back) << 16);
+                __syncthreads();
+                unsigned front_before = 0, back_before = 0, front_total = 0;
+                for(unsigned w = 0; w < BLOCK / 64; w++) {
+                    const unsigned c = s_count[w];
+                    if(w < wave) { front_before += c & 0xFFFFu; back_before += c >> 16; }
+                    front_total += c & 0xFFFFu;
+                }
+                const unsigned lane_lt = __builtin_amdgcn_mbcnt_hi((unsigned)((back ? m_back : m_front) >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)(back ? m_back : m_front), 0u));
+                if(mine) s_slot[back ? front_total + back_before + lane_lt : front_before + lane_lt] = i;
+                __syncthreads();
+                const unsigned n_here = n - q0 < (unsigned)BLOCK ? n - q0 : (unsigned)BLOCK;
+                mine = threadIdx.x < n_here;
+                i = mine ? s_slot[threadIdx.x] : 0u;
+                __syncthreads();  // (s_slot and s_count are reused by the next batch)
             }
-            const unsigned wave = threadIdx.x >> 6;
-            const unsigned long long m_back = __ballot(back), m_front = __ballot(mine && !back);
-            if((threadIdx.x & 63u) == 0u) s_count[wave] = (unsigned)__popcll(m_front) | ((unsigned)__popcll(m_back) << 16);
-            __syncthreads();
-            unsigned front_before = 0, back_before = 0, front_total = 0;
-            for(unsigned w = 0; w < BLOCK / 64; w++) {
-                const unsigned c = s_count[w];
-                if(w < wave) { front_before += c & 0xFFFFu; back_before += c >> 16; }
-                front_total += c & 0xFFFFu;
-            }
-            const unsigned lane_lt = __builtin_amdgcn_mbcnt_hi((unsigned)((back ? m_back : m_front) >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((unsigned)(back ? m_back : m_front), 0u));
-            if(mine) s_slot[back ? front_total + back_before + lane_lt : front_before + lane_lt] = i;
-            __syncthreads();
-            const unsigned n_here = n - q0 < (unsigned)BLOCK ? n - q0 : (unsigned)BLOCK;
-            mine = threadIdx.x < n_here;
-            i = mine ? s_slot[threadIdx.x] : 0u;
-            __syncthreads();  // (s_slot and s_count are reused by the next round)
+            if(!mine) continue;
+            bool continues, has_shadow;
+            unsigned null_shadow;
+            shade_vertex<RASTER, FIRST>(dp, dep, i, s_V, continues, has_shadow, null_shadow);
+            my_null += null_shadow;
+            // paths that end simply are not appended (queue compaction)
+            s_stage[u * BLOCK + threadIdx.x] = i;
+            cont_bits |= (continues ? 1u : 0u) << u;
+            shad_bits |= (has_shadow ? 1u : 0u) << u;
         }
-        if(!mine) continue;
-        bool continues, has_shadow;
-        unsigned null_shadow;
-        shade_vertex<RASTER>(dp, dep, i, s_V, continues, has_shadow, null_shadow);
-        my_null += null_shadow;
-        // paths that end simply are not appended (queue compaction)
-        if(has_shadow) {
-            const unsigned pos = atomicAdd(shadow_count, 1u);
-            shadow_queue[pos] = i;
+        // this wave's appends of the round: one counter update per queue
+        unsigned tot_c = 0u, tot_s = 0u;
+#pragma unroll 1
+        for(unsigned u = 0; u < U; u++) {
+            tot_c += (unsigned)__popcll(__ballot((cont_bits >> u) & 1u));
+            tot_s += (unsigned)__popcll(__ballot((shad_bits >> u) & 1u));
         }
-        if(continues) {
-            const unsigned pos = atomicAdd(count_out, 1u);
-            queue_out[pos] = i;
+        unsigned base_c = 0u, base_s = 0u;
+        if(lane == 0u) {
+            if(tot_c) base_c = atomicAdd(count_out, tot_c);
+            if(tot_s) base_s = atomicAdd(shadow_count, tot_s);
+        }
+        base_c = __builtin_amdgcn_readfirstlane(base_c);
+        base_s = __builtin_amdgcn_readfirstlane(base_s);
+#pragma unroll 1
+        for(unsigned u = 0; u < U; u++) {
+            const bool c = (cont_bits >> u) & 1u, sh = (shad_bits >> u) & 1u;
+            const unsigned long long m_c = __ballot(c), m_s = __ballot(sh);
+            const unsigned slot = (c || sh) ? s_stage[u * BLOCK + threadIdx.x] : 0u;
+            if(c) queue_out[base_c + __builtin_amdgcn_mbcnt_hi((unsigned)(m_c >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_c, 0u))] = slot;
+            if(sh) shadow_queue[base_s + __builtin_amdgcn_mbcnt_hi((unsigned)(m_s >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_s, 0u))] = slot;
+            base_c += (unsigned)__popcll(m_c);
+            base_s += (unsigned)__popcll(m_s);
         }
     }
     // one counter update per block (per wave they would queue up on one cache line: 32 K waves shade a 1080p vertex)
@@ -206,9 +246,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void finalize_kernel(DrawParams dp) {
             const unsigned spp = dp.samples[k].currentspp;
             if(spp != 1u) {
                 if(!have) {
-                    outDI = v3(dp.o_direct[o3], dp.o_direct[o3 + 1], dp.o_direct[o3 + 2]);
-                    outIDI = v3(dp.o_indirect[o3], dp.o_indirect[o3 + 1], dp.o_indirect[o3 + 2]);
-                    outAlbedo = v3(dp.o_albedo[o3], dp.o_albedo[o3 + 1], dp.o_albedo[o3 + 2]);
+                    const PackedF3 d = *reinterpret_cast<const PackedF3 *>(dp.o_direct + o3), q = *reinterpret_cast<const PackedF3 *>(dp.o_indirect + o3),
+                                   a = *reinterpret_cast<const PackedF3 *>(dp.o_albedo + o3);
+                    outDI = v3(d.x, d.y, d.z);
+                    outIDI = v3(q.x, q.y, q.z);
+                    outAlbedo = v3(a.x, a.y, a.z);
                 }
                 if(P.accum_mode == 1) {
                     resultDI = outDI + resultDI;
@@ -224,9 +266,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void finalize_kernel(DrawParams dp) {
             outDI = resultDI; outIDI = resultIDI; outAlbedo = albedo;
             have = true;
         }
-        dp.o_direct[o3] = outDI.x; dp.o_direct[o3 + 1] = outDI.y; dp.o_direct[o3 + 2] = outDI.z;
-        dp.o_indirect[o3] = outIDI.x; dp.o_indirect[o3 + 1] = outIDI.y; dp.o_indirect[o3 + 2] = outIDI.z;
-        dp.o_albedo[o3] = outAlbedo.x; dp.o_albedo[o3 + 1] = outAlbedo.y; dp.o_albedo[o3 + 2] = outAlbedo.z;
+        PackedF3 w;
+        w.x = outDI.x; w.y = outDI.y; w.z = outDI.z;
+        *reinterpret_cast<PackedF3 *>(dp.o_direct + o3) = w;
+        w.x = outIDI.x; w.y = outIDI.y; w.z = outIDI.z;
+        *reinterpret_cast<PackedF3 *>(dp.o_indirect + o3) = w;
+        w.x = outAlbedo.x; w.y = outAlbedo.y; w.z = outAlbedo.z;
+        *reinterpret_cast<PackedF3 *>(dp.o_albedo + o3) = w;
     }
     if(dp.snapshot && blockIdx.x == 0 && threadIdx.x == 0) {
         // queue lengths of this draw for the host's choice of the next draw's tail vertex (QueueSnapshot)
@@ -258,15 +304,20 @@ void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *
                   unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group, bool group_materials) {
     const dim3 grid(shade_grid(dp.npix)), block(SHADE_BLOCK);
     if(dep == 0 && dp.p.RasterizaionFor1st != 0)
-        hipLaunchKernelGGL((shade_kernel<1, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
+        hipLaunchKernelGGL((shade_kernel<1, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
     else if(dep == 0 && dp.raster_outputs)
-        hipLaunchKernelGGL((shade_kernel<2, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
+        hipLaunchKernelGGL((shade_kernel<2, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
     else if(group) {
         int b = (dp.npix + SHADE_GROUP_BLOCK - 1) / SHADE_GROUP_BLOCK;
         b = b < 1 ? 1 : (b > 4096 ? 4096 : b);
-        hipLaunchKernelGGL((shade_kernel<0, true>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials);
-    } else
-        hipLaunchKernelGGL((shade_kernel<0, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
+        if(dep == 0)
+            hipLaunchKernelGGL((shade_kernel<0, true, true>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials);
+        else
+            hipLaunchKernelGGL((shade_kernel<0, true, false>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials);
+    } else if(dep == 0)
+        hipLaunchKernelGGL((shade_kernel<0, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
+    else
+        hipLaunchKernelGGL((shade_kernel<0, false, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
 }
 
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,

@@ -31,14 +31,15 @@ __device__ __forceinline__ void apply_sky_sample(const ShadowEntry *shadow, cons
     const float4 e0 = e[0], e1 = e[1];
     if(!(h.tri < 0 || h.t * h.t > e0.w)) return;  // occluded
     const float4 t0 = *reinterpret_cast<const float4 *>(thr + px);
-    PathAccum *a = acc + px;
-    a->gi[0] = a->gi[0] + t0.x * e1.x;
-    a->gi[1] = a->gi[1] + t0.y * e1.y;
-    a->gi[2] = a->gi[2] + t0.z * e1.z;
-    if(__float_as_uint(e1.w) & 2u) {
-        a->di[0] = e1.x;
-        a->di[1] = e1.y;
-        a->di[2] = e1.z;
+    float4 *a = reinterpret_cast<float4 *>(acc + px);
+    float4 g = a[1];  // gi and its padding word: one load, one store
+    g.x = g.x + t0.x * e1.x;
+    g.y = g.y + t0.y * e1.y;
+    g.z = g.z + t0.z * e1.z;
+    a[1] = g;
+    if(__float_as_uint(e1.w) & 2u) {  // di (first_exist behind it stays)
+        struct __attribute__((packed, aligned(4))) F3 { float x, y, z; } d = {e1.x, e1.y, e1.z};
+        *reinterpret_cast<F3 *>(acc + px) = d;
     }
 }
 

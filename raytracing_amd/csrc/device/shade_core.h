@@ -132,6 +132,12 @@ __device__ __forceinline__ int wrap_texel(float f, int n) {
     return m < 0 ? m + n : m;
 }
 
+// One texel = ONE load instruction wherever the format allows: a gather costs the memory pipeline a pass per distinct
+// cache line among the 64 lanes whatever its width, so three dword loads of one 12-byte texel cost three times one
+// 12-byte load.  (Global loads wider than a dword need dword alignment only; a dword load needs none.)
+struct __attribute__((packed, aligned(4))) PackedF3 { float x, y, z; };
+struct __attribute__((packed, aligned(4))) PackedF4 { float x, y, z, w; };
+
 __device__ __forceinline__ V3 fetch_texel_rgb(const TexDesc &tx, int x, int y) {
     size_t base = ((size_t)y * tx.width + x) * tx.channels;
     float c[3] = {0.0f, 0.0f, 0.0f};
@@ -141,6 +147,20 @@ __device__ __forceinline__ V3 fetch_texel_rgb(const TexDesc &tx, int x, int y) {
         c[0] = (float)(w & 0xFFu) / 255.0f;
         c[1] = (float)((w >> 8) & 0xFFu) / 255.0f;
         c[2] = (float)((w >> 16) & 0xFFu) / 255.0f;
+#ifndef RT_PACKED_LOADS
+#define RT_PACKED_LOADS 1
+#endif
+    } else if(RT_PACKED_LOADS && tx.format == 0 && tx.channels == 3) {
+        // RGB8: three bytes at any alignment, read as one (unaligned) word; the fourth byte is the next texel's, or
+        // the padding pt_tex_create leaves behind the last one
+        unsigned w;
+        __builtin_memcpy(&w, static_cast<const unsigned char *>(tx.data) + base, 4);
+        c[0] = (float)(w & 0xFFu) / 255.0f;
+        c[1] = (float)((w >> 8) & 0xFFu) / 255.0f;
+        c[2] = (float)((w >> 16) & 0xFFu) / 255.0f;
+    } else if(RT_PACKED_LOADS && tx.format == 1 && tx.channels == 3) {
+        const PackedF3 t = *reinterpret_cast<const PackedF3 *>(static_cast<const float *>(tx.data) + base);
+        c[0] = t.x; c[1] = t.y; c[2] = t.z;
     } else if(tx.format == 0) {
         const unsigned char *p = static_cast<const unsigned char *>(tx.data) + base;
         for(int k = 0; k < 3; k++)
@@ -204,11 +224,14 @@ struct ShadeCtx {
     V3 m_albedo;
 
     __device__ void bind_material(int mptr, float uvx, float uvy) {
-        m_type = materials[mptr];
-        m_albedo = v3(materials[mptr + 1], materials[mptr + 2], materials[mptr + 3]);
-        m_alpha = materials[mptr + 4];
-        m_metallic = materials[mptr + 5];
-        const int albedo_map = roundint(materials[mptr + 6]);
+        // seven floats in two loads (the record sits at any multiple of four bytes)
+        const PackedF4 ma = *reinterpret_cast<const PackedF4 *>(materials + mptr);
+        const PackedF3 mb = *reinterpret_cast<const PackedF3 *>(materials + mptr + 4);
+        m_type = ma.x;
+        m_albedo = v3(ma.y, ma.z, ma.w);
+        m_alpha = mb.x;
+        m_metallic = mb.y;
+        const int albedo_map = roundint(mb.z);
         m_eta = roundint(m_type) == 2 ? materials[mptr + 7] : 0.0f;  // (conductor records end after 7 floats)
         if(albedo_map >= 0 && albedo_map < n_textures) m_albedo = powv(texture_rgb(textures[albedo_map], uvx, uvy), 2.2f);
     }

@@ -43,6 +43,21 @@ __device__ __forceinline__ bool state_pixel(const DrawParams &dp, unsigned i, un
     return px < (unsigned)dp.W && py < (unsigned)dp.H;
 }
 
+// the four last-write outputs of a pixel (:672-688), one store each: the eight pixels of a tile row are neighbours in
+// every one of them
+__device__ __forceinline__ void store_gbuffer(const DrawParams &dp, size_t pix, float motion_x, float motion_y, float depth, V3 normal,
+                                              float instance) {
+#if defined(RT_X) && RT_X == 1
+    if(depth != 12345.0f) return;
+#endif
+    *reinterpret_cast<float2 *>(dp.o_motion + pix * 2) = make_float2(motion_x, motion_y);
+    dp.o_depth[pix] = depth;
+    PackedF3 n;
+    n.x = normal.x; n.y = normal.y; n.z = normal.z;
+    *reinterpret_cast<PackedF3 *>(dp.o_normal + pix * 3) = n;
+    dp.o_inst[pix] = instance;
+}
+
 __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V3 recv, unsigned flags) {
     float4 *p = reinterpret_cast<float4 *>(e);
     p[0] = make_float4(d.x, d.y, d.z, dis2);
@@ -61,7 +76,9 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 //   1  RasterizaionFor1st: they ARE the first hit, no primary ray was traced;
 //   2  RasterizaionFor1st off with the depth and instance-index images bound: the first hit is traced, but the
 //      depth output is the raster depth and the albedo is looked up through the raster instance index, as there.
-template <int RASTER>
+// FIRST: dep == 0, known when the kernel is compiled: the launch of vertex 0 carries none of the code of later vertices
+// (throughput update, escape to the sky) and the launches of later vertices none of the first-hit outputs.
+template <int RASTER, bool FIRST>
 __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsigned i, const unsigned *s_T, bool &continues,
                                              bool &has_shadow, unsigned &null_shadow) {
     continues = false;
@@ -75,10 +92,20 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     // motion, depth, normal and instance index keep what the LAST sample wrote (:672-688 overwrite them per draw)
     const bool writes_gbuffer = sample_k + 1u == (unsigned)dp.batch;
 
-    const float4 *rp = reinterpret_cast<const float4 *>(dp.rays + i);
-    const float4 r0 = rp[0], r1 = rp[1];
-    const V3 ray_o = v3(r0.x, r0.y, r0.z), ray_d = v3(r1.x, r1.y, r1.z);
-    const float prev_cos = r0.w;  // |wo.z| of the BSDF sample this ray follows
+    // Vertex 0 needs nothing of the path state but the hit: its ray is the pixel's camera ray, made again here with the
+    // arithmetic that made it for the traversal (no rounding depends on where it runs), its throughput is 1, its sampler
+    // dimension 1 (:602), its accumulators start at zero -- so the launches that make the camera rays store none of that.
+    V3 ray_o, ray_d;
+    float prev_cos = 0.0f;  // |wo.z| of the BSDF sample this ray follows
+    if(FIRST) {
+        camera_ray(P, dp.samples[sample_k].jitter[0], dp.samples[sample_k].jitter[1], dp.tan_half_fov, px, py, ray_o, ray_d);
+    } else {
+        const float4 *rp = reinterpret_cast<const float4 *>(dp.rays + i);
+        const float4 r0 = rp[0], r1 = rp[1];
+        ray_o = v3(r0.x, r0.y, r0.z);
+        ray_d = v3(r1.x, r1.y, r1.z);
+        prev_cos = r0.w;
+    }
     // RasterizaionFor1st: the first hit comes from the raster pass's images (:606-624), no
     // primary ray was traced
     const bool raster0 = RASTER == 1;
@@ -107,8 +134,15 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         hit_inst = __float_as_int(h1.x);
         exist = hit_tri >= 0;
     }
+#if defined(RT_X) && RT_X == 3
+    if(FIRST) { if(exist) dp.o_inst[pix] = hit_t; return; }
+#endif
     float4 *tp = reinterpret_cast<float4 *>(dp.thr + i);
-    const float4 t0 = tp[0], t1 = tp[1];
+    float4 t0 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), t1 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(1u));
+    if(!FIRST) {
+        t0 = tp[0];
+        t1 = tp[1];
+    }
     V3 history = v3(t0.x, t0.y, t0.z);
     const float prev_pdf = t0.w;
     const V3 prev_fr = v3(t1.x, t1.y, t1.z);
@@ -130,7 +164,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
 
     float raster_depth = 0.0f;
     int raster_inst = -1;
-    if(RASTER == 2 && dep == 0) {
+    if(RASTER == 2 && FIRST) {
         const float suv_x0 = ((float)px + 0.5f) / (float)dp.W, suv_y0 = ((float)py + 0.5f) / (float)dp.H;
         const float wu = suv_x0 * (float)dp.W / (float)P.WINDOW_W;
         const float wv = (suv_y0 - 1.0f) * (float)dp.H / (float)P.WINDOW_H + 1.0f;
@@ -138,7 +172,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         raster_inst = float_to_int(texture_nearest_r(dp.gb_inst, wu, wv) + 0.01f);
     }
 
-    if(dep == 0) {
+    if(FIRST) {
         if(!exist) {
             // :496-499 and the G-buffer writes of :672-688 for a miss
             const V3 bg = cx.get_background_color(ray_d);
@@ -154,13 +188,8 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
             const float ny = (bp[1] * mp.x + bp[5] * mp.y) + (bp[9] * mp.z + bp[13]);
             const float nw = (bp[3] * mp.x + bp[7] * mp.y) + (bp[11] * mp.z + bp[15]);
             const float suv_x = ((float)px + 0.5f) / (float)dp.W, suv_y = ((float)py + 0.5f) / (float)dp.H;
-            dp.o_motion[pix * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
-            dp.o_motion[pix * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
-            dp.o_depth[pix] = raster0 ? hit_t : (RASTER == 2 ? raster_depth : 1000000.0f);
-            dp.o_normal[pix * 3] = g_normal.x;
-            dp.o_normal[pix * 3 + 1] = g_normal.y;
-            dp.o_normal[pix * 3 + 2] = g_normal.z;
-            dp.o_inst[pix] = raster0 ? (float)hit_inst : -1.0f;
+            store_gbuffer(dp, pix, suv_x - (nx / nw + 1.0f) / 2.0f, suv_y - (ny / nw + 1.0f) / 2.0f,
+                          raster0 ? hit_t : (RASTER == 2 ? raster_depth : 1000000.0f), g_normal, raster0 ? (float)hit_inst : -1.0f);
             return;
         }
     } else {
@@ -170,15 +199,18 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
                 if(skyS) recv = recv / (prev_pdf + cx.skybox_sample_pdf(ray_d));
                 else recv = recv / prev_pdf;
                 const V3 add = history * recv;
-                acc->gi[0] += add.x;
-                acc->gi[1] += add.y;
-                acc->gi[2] += add.z;
+                float4 *ag = reinterpret_cast<float4 *>(acc) + 1;   // gi and its padding word: one load, one store
+                float4 g = *ag;
+                g.x += add.x;
+                g.y += add.y;
+                g.z += add.z;
+                *ag = g;
             }
             return;
         }
         history = history * (prev_fr * prev_cos / prev_pdf);  // :579
     }
-    if(dep >= P.MAX_DEPTH && dep != 0) return;  // loop bound of :501 (the first hit's outputs are due even at MAX_DEPTH 0)
+    if(!FIRST && dep >= P.MAX_DEPTH) return;  // loop bound of :501 (the first hit's outputs are due even at MAX_DEPTH 0)
 
     // ---- geometry of the hit (what intersect_triangle / intersect_meshBVH return, :239-248, :275-276)
     // first 64 bytes of the instance record: rows of world-to-local, then root, material pointer
@@ -204,7 +236,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     const int materialPtr = __float_as_int(ir3.y);  // InstAccel::material_ptr
 
     cx.bind_material(materialPtr, uvx, uvy);
-    if(dep == 0) {
+    if(FIRST) {
         // first-hit outputs, :640-655 and :682-688
         BSDFQueryRecord ab;
         ab.wi = v3(0.0f); ab.wo = v3(0.0f); ab.mptr = materialPtr; ab.uvx = uvx; ab.uvy = uvy; ab.eta = 1.0f;
@@ -219,27 +251,28 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         } else {
             albedo = cx.albedo_material(ab);
         }
-        acc->albedo[0] = albedo.x;
-        acc->albedo[1] = albedo.y;
-        acc->albedo[2] = albedo.z;
-        acc->first_exist = 1.0f;
+        {
+            // (direct and accumulated light start at zero; first_exist = 1)
+            float4 *a = reinterpret_cast<float4 *>(acc);
+            a[0] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            a[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            a[2] = make_float4(albedo.x, albedo.y, albedo.z, 0.0f);
+        }
         if(writes_gbuffer) {
             const float *bp = P.backprojMat;
             const float nx = (bp[0] * position.x + bp[4] * position.y) + (bp[8] * position.z + bp[12]);
             const float ny = (bp[1] * position.x + bp[5] * position.y) + (bp[9] * position.z + bp[13]);
             const float nw = (bp[3] * position.x + bp[7] * position.y) + (bp[11] * position.z + bp[15]);
             const float suv_x = ((float)px + 0.5f) / (float)dp.W, suv_y = ((float)py + 0.5f) / (float)dp.H;
-            dp.o_motion[pix * 2] = suv_x - (nx / nw + 1.0f) / 2.0f;
-            dp.o_motion[pix * 2 + 1] = suv_y - (ny / nw + 1.0f) / 2.0f;
-            dp.o_depth[pix] = RASTER == 2 ? raster_depth : hit_t;
-            dp.o_normal[pix * 3] = normal.x;
-            dp.o_normal[pix * 3 + 1] = normal.y;
-            dp.o_normal[pix * 3 + 2] = normal.z;
-            dp.o_inst[pix] = (float)hit_inst;
+            store_gbuffer(dp, pix, suv_x - (nx / nw + 1.0f) / 2.0f, suv_y - (ny / nw + 1.0f) / 2.0f,
+                          RASTER == 2 ? raster_depth : hit_t, normal, (float)hit_inst);
         }
         if(dep >= P.MAX_DEPTH) return;
     }
 
+#if defined(RT_X) && RT_X == 4
+    if(FIRST) { tp[0] = make_float4(normal.x, position.y, cx.m_albedo.x, cx.m_alpha); return; }
+#endif
     // ---- :507-513
     const Frame coord = create_coord(normal);
     BSDFQueryRecord bRec;
@@ -249,7 +282,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     bRec.uvx = uvx;
     bRec.uvy = uvy;
     bRec.eta = 1.0f;
-    const unsigned first_bit = dep == 0 ? 2u : 0u;
+    const unsigned first_bit = FIRST ? 2u : 0u;
     bool any_shadow = false, null_sample = false;
     unsigned null_count = 0u;  // light samples of this vertex that are exactly zero
     float pdf;
@@ -299,7 +332,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         const V3 recv = radiance * fr * fabsf(bRec.wo.z);
         // (a sample that is exactly zero -- a light behind the surface -- as for the sky's above; not at vertex 0,
         // where a visible sample, zero or not, replaces the direct light an earlier one has set, :551-552)
-        const bool null_light = dep > 0 && (__float_as_uint(recv.x) | __float_as_uint(recv.y) | __float_as_uint(recv.z)) == 0u &&
+        const bool null_light = !FIRST && (__float_as_uint(recv.x) | __float_as_uint(recv.y) | __float_as_uint(recv.z)) == 0u &&
                                 fabsf(history.x) <= 3.4028235e38f && fabsf(history.y) <= 3.4028235e38f && fabsf(history.z) <= 3.4028235e38f;
         write_shadow(dp.shadow + (size_t)(1 + li) * dp.npix + i, dir, dis2, recv, null_light ? 0u : (1u | first_bit));
         if(null_light) null_count++;

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) RT_TAIL_OCC void path_tail_kernel(FastS
         for(int dep = dep0;; dep++) {
             bool continues = false, has_shadow = false;
             unsigned null_shadow = 0u;  // (0 or 1 here: this launch runs with the sky as the only light)
-            if(alive) shade_vertex<0>(dp, dep, slot, s_T, continues, has_shadow, null_shadow);
+            if(alive) shade_vertex<0, false>(dp, dep, slot, s_T, continues, has_shadow, null_shadow);   // (dep0 >= 1)
             alive = continues;
             const unsigned long long m_c = __ballot(continues), m_s = __ballot(has_shadow);
             n_null += (unsigned)__popcll(__ballot(null_shadow != 0u));

@@ -154,20 +154,32 @@ struct PrimarySource {
         if(!state_pixel(dp, i, px, py, k)) return false;  // a slot of an edge tile that names no pixel: nobody reads it
         V3 ro, rd;
         camera_ray(dp.p, dp.samples[k].jitter[0], dp.samples[k].jitter[1], dp.tan_half_fov, px, py, ro, rd);
-        float4 *r = reinterpret_cast<float4 *>(dp.rays + i);
-        r[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-        r[1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-        float4 *t = reinterpret_cast<float4 *>(dp.thr + i);
-        t[0] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        t[1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(1u));  // sobolcurdim = 1, :602
-        float4 *a = reinterpret_cast<float4 *>(dp.acc + i);
-        a[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        a[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        a[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // (nothing of the path state is stored: the launch that shades vertex 0 makes the same ray again and knows
+        // what throughput, sampler dimension and accumulators start with; a ray the reference-order traversal has to
+        // trace again is stored by the sink)
         o[0] = ro.x; o[1] = ro.y; o[2] = ro.z;
         d[0] = rd.x; d[1] = rd.y; d[2] = rd.z;
         any_hit = false;
         return true;
+    }
+};
+
+struct PrimarySinkFast {
+    const DrawParams &dp;
+    unsigned *redo, *redo_count;
+    __device__ void store(unsigned i, const LaneHit &h, bool ambiguous) const {
+        write_path_hit(dp.hits, i, h);  // (provisional for an ambiguous ray: bounds its second pass)
+        if(ambiguous) {
+            // the reference-order launch behind this one reads its rays from the path state: store this one
+            unsigned px, py, k;
+            state_pixel(dp, i, px, py, k);
+            V3 ro, rd;
+            camera_ray(dp.p, dp.samples[k].jitter[0], dp.samples[k].jitter[1], dp.tan_half_fov, px, py, ro, rd);
+            float4 *r = reinterpret_cast<float4 *>(dp.rays + i);
+            r[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+            r[1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+            redo[atomicAdd(redo_count, 1u)] = i;
+        }
     }
 };
 
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_fast_kernel(Fa
         dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
     }
     PrimarySource src{dp};
-    ExtendSinkFast sink{nullptr, dp.hits, redo, redo_count};
+    PrimarySinkFast sink{dp, redo, redo_count};
     trace_fast_any<MODE>(sc, src, sink, next_counter, (unsigned)dp.npix, s_stack);
 }
 
