@@ -48,9 +48,11 @@ def parse():
     ap.add_argument("--textures", type=int, default=0, help="synth_pt: number of procedural RGBA8 albedo maps")
     ap.add_argument("--texture-size", type=int, default=4096)
     ap.add_argument("--rays", type=int, default=1 << 24, help="casa_isect: rays per step")
-    ap.add_argument("--pipeline", type=int, default=2, help="draws in flight on the device (pt_pass_set_pipeline)")
-    ap.add_argument("--batch", type=int, default=8,
-                    help="samples per pt_pass_draw_batch call (1..16): the samples of a frame share the launches of one draw")
+    ap.add_argument("--pipeline", type=int, default=3, help="draws in flight on the device (pt_pass_set_pipeline); HIP's default of 4 "
+                                                            "hardware queues per process holds three and the context's own stream")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="samples per pt_pass_draw_batch call (1..16): the samples of a frame share the launches of one draw; 0 (default) "
+                         "= the rank's samples cut evenly over the draws in flight, at most 16 per draw")
     ap.add_argument("--wide-nodes", type=int, default=-1, choices=[-1, 0, 1],
                     help="node format of the ordered traversal (pt_pass_set_wide_nodes): -1 library default, 0 fp32, 1 quantised")
     ap.add_argument("--hw-queues", type=int, default=0,
@@ -128,7 +130,10 @@ def main():
     from raytracing_amd import device, multigpu, scene
 
     wl = args.workload
-    steps = args.steps if args.steps is not None else (64 if wl == "casa_pt" else (8 if wl == "casa_isect" else 16))
+    steps = args.steps if args.steps is not None else (96 if wl == "casa_pt" else (8 if wl == "casa_isect" else 18))
+    if args.batch <= 0:
+        mine = steps if (world == 1 or args.scaling == "weak") else -(-steps // world)
+        args.batch = max(1, min(16, -(-mine // max(args.pipeline, 1))))
     warmup = args.warmup if args.warmup is not None else {"casa_pt": 16, "casa_isect": 2}.get(wl, 4)
 
     t_setup = time.time()
@@ -311,15 +316,27 @@ def main():
                 each.append((time.perf_counter() - t1) * 1e3)
             # (the median: one draw that meets a busy host thread or a clock ramp does not move it; the mean rides along)
             serial_ms, serial_mean_ms = float(np.median(each)), float(np.mean(each))
-            # (b) per-kernel times of the vertex-by-vertex chain (tail launch off, so that every ray of the
-            #     draws is traced by the kernels that are timed)
+            # (a') the same with the samples drawn as the timed region draws them (batches), one draw in flight
+            batch_ms = None
+            if args.batch > 1:
+                bp = timed_params[:args.batch * 3]
+                p.draw_batch(bp[:args.batch])
+                ctx.synchronize()
+                each_b = []
+                for k in range(0, len(bp), args.batch):
+                    t1 = time.perf_counter()
+                    p.draw_batch(bp[k:k + args.batch])
+                    ctx.synchronize()
+                    each_b.append((time.perf_counter() - t1) * 1e3 / len(bp[k:k + args.batch]))
+                batch_ms = float(np.median(each_b))
+            # (b) per-kernel times: the draws of the timed region once more (same batches), one at a time, with events around
+            #     every launch (tail launch off, so that every ray is traced by the kernels that are timed)
             p.set_tail_threshold(0)
             p.set_profiling(True)
             p.profile(reset=True)
             p.stats(reset=True)
-            for prm in prof_params:
-                p.set_params(prm)
-                p.draw()
+            ev_params = timed_params[:max(args.batch, 1) * 2] if args.batch > 1 else prof_params
+            draw_all(ev_params)
             ctx.synchronize()
             prof = p.profile()
             pst = p.stats(reset=True)
@@ -327,6 +344,8 @@ def main():
             p.set_tail_threshold(args.tail)
             p.set_pipeline(args.pipeline)
             note("per-kernel profiling pass done")
+            prof["samples_timed"] = len(ev_params)
+            prof["batch_ms_per_step"] = batch_ms
             prof["draws"] = n_prof
             prof["serial_ms_per_step"] = serial_ms
             prof["serial_mean_ms_per_step"] = serial_mean_ms
@@ -493,6 +512,9 @@ def main():
                         # total bytes of those kernels over the profiled run / number of main launches
                         tot = sum((pmc[n]["FETCH_SIZE"]["total"] + pmc[n]["WRITE_SIZE"]["total"]) * 1024.0 for n in have)
                         n_launch = sum(pmc[n]["FETCH_SIZE"]["launches"] for n in main)
+                        if pmc.get("_meta", {}).get("hbm_bytes_per_sample"):
+                            # every kernel of a frame's sample (traversal, shading, finalize): bytes that crossed the HBM interface
+                            out["hbm_bytes_per_sample_measured"] = pmc["_meta"]["hbm_bytes_per_sample"]
                         rf["traffic"] = tot / max(n_launch, 1)
                         rf["traffic_source"] = "profiles/" + os.path.basename(pmc_file)
                         rf["algorithmic_bytes_per_launch"] = rf["rays_per_launch"] * b_ray
@@ -523,11 +545,15 @@ def main():
                 out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "trace_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms", "tail_ms")}
                 if "draws" in prof:
                     out["kernel_ms"]["over_draws"] = prof["draws"]
+                    out["kernel_ms"]["over_samples"] = prof["samples_timed"]
+                    # a caller that draws ONE sample, waits, consumes (the reference's loop shape with Config::SPP = 1) ...
                     out["kernel_ms"]["one_draw_in_flight_ms_per_step"] = prof["serial_ms_per_step"]
+                    # ... and one that hands the frame's samples over in batches (pt_pass_draw_batch) and waits for each batch
+                    out["kernel_ms"]["one_batch_in_flight_ms_per_step"] = prof["batch_ms_per_step"]
                     out["kernel_ms"]["one_draw_in_flight_mean_ms_per_step"] = prof["serial_mean_ms_per_step"]
                     if b_ray is not None:
                         # what the whole pipelined frame sustains, extend rays only
-                        out["roofline"]["measured_on"] = "%d draws issued one at a time after the timed region" % prof["draws"]
+                        out["roofline"]["measured_on"] = "%d samples drawn again after the timed region, in the same batches, one draw in flight, HIP events around every launch" % prof["samples_timed"]
         print(json.dumps(out), flush=True)
 
     if wl != "casa_isect" and comm is not None:

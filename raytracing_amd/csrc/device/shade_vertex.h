@@ -47,9 +47,6 @@ __device__ __forceinline__ bool state_pixel(const DrawParams &dp, unsigned i, un
 // every one of them
 __device__ __forceinline__ void store_gbuffer(const DrawParams &dp, size_t pix, float motion_x, float motion_y, float depth, V3 normal,
                                               float instance) {
-#if defined(RT_X) && RT_X == 1
-    if(depth != 12345.0f) return;
-#endif
     *reinterpret_cast<float2 *>(dp.o_motion + pix * 2) = make_float2(motion_x, motion_y);
     dp.o_depth[pix] = depth;
     PackedF3 n;
@@ -134,9 +131,6 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         hit_inst = __float_as_int(h1.x);
         exist = hit_tri >= 0;
     }
-#if defined(RT_X) && RT_X == 3
-    if(FIRST) { if(exist) dp.o_inst[pix] = hit_t; return; }
-#endif
     float4 *tp = reinterpret_cast<float4 *>(dp.thr + i);
     float4 t0 = make_float4(1.0f, 1.0f, 1.0f, 0.0f), t1 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(1u));
     if(!FIRST) {
@@ -270,9 +264,6 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         if(dep >= P.MAX_DEPTH) return;
     }
 
-#if defined(RT_X) && RT_X == 4
-    if(FIRST) { tp[0] = make_float4(normal.x, position.y, cx.m_albedo.x, cx.m_alpha); return; }
-#endif
     // ---- :507-513
     const Frame coord = create_coord(normal);
     BSDFQueryRecord bRec;

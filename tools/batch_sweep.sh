@@ -2,10 +2,10 @@
 # casa 1080p depth 8, HIP's default hardware queues: samples per draw x draws in flight.
 # usage: tools/batch_sweep.sh OUT_PREFIX [extra bench.py arguments]
 out=$1; shift
-for cfg in "1 1" "1 3" "2 1" "4 1" "8 1" "16 1" "2 3" "4 3" "8 3" "4 2" "8 2" "16 2"; do
-  set -- $cfg "${@:3}"
-  b=$1; pl=$2
-  timeout -k 10 120 python bench.py --hw-queues 0 --batch $b --pipeline $pl --steps 64 --warmup 16 --no-cpu-baseline --no-profile "${@:3}" \
+# environment: CFGS="batch:pipeline ..." STEPS WARMUP
+for cfg in ${CFGS:-1:1 1:3 4:1 16:1 4:3 8:2 8:3 16:2 16:3}; do
+  b=${cfg%%:*}; pl=${cfg##*:}
+  timeout -k 10 120 python bench.py --hw-queues 0 --batch $b --pipeline $pl --steps ${STEPS:-256} --warmup ${WARMUP:-32} --no-cpu-baseline --no-profile "$@" \
      > ${out}_b${b}_p${pl}.json 2>> ${out}.err || exit 1
   python - <<PY
 import json

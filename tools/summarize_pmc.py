@@ -1,5 +1,6 @@
 """Sums rocprofv3 --pmc counter CSVs per kernel name.
-Usage: summarize_pmc.py <dir> [kernel substring] [--json out.json]
+Usage: summarize_pmc.py <dir> [kernel substring] [--json out.json] [--samples N]
+(--samples: how many samples per pixel the profiled run drew, warm-up included; stored so that bytes per sample can be quoted)
 With --json, also writes {kernel: {counter: {"total":, "launches":}}} plus HBM bytes per launch
 (FETCH_SIZE and WRITE_SIZE are in KiB; for this library's access pattern -- 64-byte records
 gathered with four 16-byte loads per lane -- tools/calib/fetch_calib.hip measured FETCH_SIZE
@@ -10,6 +11,9 @@ import json
 import sys
 from collections import defaultdict
 
+samples = int(sys.argv[sys.argv.index("--samples") + 1]) if "--samples" in sys.argv else None
+if samples is not None:
+    del sys.argv[sys.argv.index("--samples"):sys.argv.index("--samples") + 2]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 d = args[0]
 sub = args[1] if len(args) > 1 and not args[1].endswith(".json") else ""
@@ -43,4 +47,10 @@ if jout:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from raytracing_amd.build import kernel_sources_digest
     out["_meta"] = {"kernel_sources_sha256": kernel_sources_digest()}
+    if samples:
+        # every kernel of the run, the library's and the runtime's fills / copies: HBM bytes per sample per pixel-frame
+        fetch = sum(tot[k].get("FETCH_SIZE", 0.0) for k in tot) * 1024.0
+        write = sum(tot[k].get("WRITE_SIZE", 0.0) for k in tot) * 1024.0
+        out["_meta"].update({"samples": samples, "hbm_bytes_per_sample": (fetch + write) / samples,
+                             "hbm_read_bytes_per_sample": fetch / samples, "hbm_written_bytes_per_sample": write / samples})
     json.dump(out, open(jout, "w"), indent=1, sort_keys=True)
