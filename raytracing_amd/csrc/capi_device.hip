@@ -1151,6 +1151,10 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     HIP_TRY(hipMemsetAsync(cnt, 0, CNT_TOTAL * 4, s));
     // camera rays: a launch of their own, unless the ordered extend of vertex 0 makes them where it traces them
     const bool fused_primary = ordered && !raster_first;
+    // camera rays of a tile walk the flattened tree together when its deepest walk fits the wave's stack (RTA_PRIMARY_PACKETS=0:
+    // one ray per lane, a tuning aid)
+    static const bool packets_wanted = !(getenv("RTA_PRIMARY_PACKETS") && atoi(getenv("RTA_PRIMARY_PACKETS")) == 0);
+    const bool packets = packets_wanted && fsc.flat_buf != nullptr && p->flat.max_stack + 2 <= packet_stack_entries();
     if(!fused_primary) {
         ScopedTimer t(p, K_OTHER);
         launch_generate(s, dp);
@@ -1170,7 +1174,7 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
         ScopedTimer t(p, K_EXTEND);
         if(ordered) {
             if(dep == 0 && fused_primary)
-                launch_primary_fast(s, fsc, grid, dp, cnt + CNT_NEXT + 2 * dep, qr, cnt + CNT_REDO + dep);
+                launch_primary_fast(s, fsc, grid, dp, cnt + CNT_NEXT + 2 * dep, qr, cnt + CNT_REDO + dep, packets);
             else
                 launch_extend_fast(s, fsc, grid, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, qr,
                                    cnt + CNT_REDO + dep);

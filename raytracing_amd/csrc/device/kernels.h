@@ -129,8 +129,11 @@ void launch_path_tail(hipStream_t s, const FastScene &fsc, const TraceScene &tsc
 int tail_paths_per_block();
 void launch_generate(hipStream_t s, const DrawParams &dp);
 // generate + the ordered extend of vertex 0 in one launch (camera rays made where they are traced)
+// packets: over the flattened tree, one wave per tile of 64 slots walking one node sequence (trace_packet.h); the tree's
+// deepest walk must fit packet_stack_entries() deferred nodes
 void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter, unsigned *redo,
-                         unsigned *redo_count);
+                         unsigned *redo_count, bool packets);
+int packet_stack_entries();
 // shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to
 // queue_out and paths with pending light samples to shadow_queue.
 // group: every block first sorts its 256 paths into two groups, so that at most one of its four waves runs the code

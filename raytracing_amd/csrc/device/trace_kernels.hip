@@ -7,6 +7,7 @@
 #include "shade_vertex.h"
 #include "trace_fast.h"
 #include "trace_flat.h"
+#include "trace_packet.h"
 
 namespace rta {
 namespace {
@@ -196,6 +197,19 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_fast_kernel(Fa
     PrimarySource src{dp};
     PrimarySinkFast sink{dp, redo, redo_count};
     trace_fast_any<MODE>(sc, src, sink, next_counter, (unsigned)dp.npix, s_stack);
+}
+
+// The same launch for a pass that walks the flattened tree: one wave per tile of 64 slots, all lanes on one node
+// sequence (trace_packet.h).  No LDS.
+__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_packet_kernel(FastScene sc, DrawParams dp, unsigned *next_counter,
+                                                                    unsigned *redo, unsigned *redo_count) {
+    if(blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch);
+        atomicAdd(&dp.stats[3], (unsigned long long)dp.batch);
+        dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
+    }
+    PrimarySinkFast sink{dp, redo, redo_count};
+    trace_flat_packets(sc, dp, sink, next_counter, (unsigned)dp.npix);
 }
 
 // ---- shadow ------------------------------------------------------------------------------
@@ -401,10 +415,14 @@ void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, cons
 }
 
 void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter, unsigned *redo,
-                         unsigned *redo_count) {
-    hipLaunchKernelGGL(RT_PICK_FAST(primary_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp,
-                       next_counter, redo, redo_count);
+                         unsigned *redo_count, bool packets) {
+    if(packets && sc.flat_buf)
+        hipLaunchKernelGGL(primary_packet_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp, next_counter, redo, redo_count);
+    else
+        hipLaunchKernelGGL(RT_PICK_FAST(primary_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp,
+                           next_counter, redo, redo_count);
 }
+int packet_stack_entries() { return PACKET_STACK; }
 
 void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n,
                       const unsigned *redo, const unsigned *redo_count, pt_hit *hits, unsigned *next_counter,
