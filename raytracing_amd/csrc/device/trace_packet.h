@@ -181,36 +181,45 @@ __device__ __forceinline__ void trace_flat_packets(const FastScene &sc, const Dr
                 RT_QBOX(3, t3, x3);
 #undef RT_QBOX
 #undef RT_Q
-                unsigned r0 = __float_as_uint(q1.z), r1 = __float_as_uint(q1.w), r2 = __float_as_uint(q2.x), r3 = __float_as_uint(q2.y);
-                // per child: the smallest entry distance among the lanes whose ray passes it (no lane: 0xFFFFFFFF)
-                unsigned k0 = wave_umin(live && relaxed_pass(t0, x0) && t0 <= prune_t ? __float_as_uint(t0) : 0xFFFFFFFFu);
-                unsigned k1 = wave_umin(live && relaxed_pass(t1, x1) && t1 <= prune_t ? __float_as_uint(t1) : 0xFFFFFFFFu);
-                unsigned k2 = wave_umin(r2 != REF_NONE && live && relaxed_pass(t2, x2) && t2 <= prune_t ? __float_as_uint(t2) : 0xFFFFFFFFu);
-                unsigned k3 = wave_umin(r3 != REF_NONE && live && relaxed_pass(t3, x3) && t3 <= prune_t ? __float_as_uint(t3) : 0xFFFFFFFFu);
-                auto order = [](unsigned &ka, unsigned &ra, unsigned &kb, unsigned &rb) {
-                    const bool sw = kb < ka;
-                    const unsigned kl = sw ? kb : ka, kh = sw ? ka : kb, rl = sw ? rb : ra, rh = sw ? ra : rb;
-                    ka = kl; kb = kh; ra = rl; rb = rh;
-                };
-                order(k0, r0, k1, r1);
-                order(k2, r2, k3, r3);
-                order(k0, r0, k2, r2);
-                order(k1, r1, k3, r3);
-                order(k1, r1, k2, r2);
-                auto push = [&](unsigned r, unsigned key) {
-                    if(sp < PACKET_STACK) {
-                        if((int)lane == sp) {  // (one select each: lane sp takes the entry)
-                            st_ref = (int)r;
-                            st_key = (int)key;
-                        }
-                        ++sp;
-                    } else {
-                        *sc.error_flag = 1u;
-                    }
-                };
-                if(k0 == 0xFFFFFFFFu) {
+                // the four references are the same in every lane: as scalars, so that choosing among them costs no vector work
+                unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q1.z)), r1 = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q1.w));
+                unsigned r2 = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q2.x)), r3 = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q2.y));
+                const bool p0 = live && relaxed_pass(t0, x0) && t0 <= prune_t, p1 = live && relaxed_pass(t1, x1) && t1 <= prune_t;
+                const bool p2 = r2 != REF_NONE && live && relaxed_pass(t2, x2) && t2 <= prune_t, p3 = r3 != REF_NONE && live && relaxed_pass(t3, x3) && t3 <= prune_t;
+                const bool a0 = __any(p0), a1 = __any(p1), a2 = __any(p2), a3 = __any(p3);
+                const int n_pass = (int)a0 + (int)a1 + (int)a2 + (int)a3;
+                if(n_pass == 0) {
                     have = false;
+                } else if(n_pass == 1) {
+                    // the common case deep in the tree: one child, nothing to order, nothing to defer
+                    ref = a0 ? r0 : (a1 ? r1 : (a2 ? r2 : r3));
                 } else {
+                    // per child: the smallest entry distance among the lanes whose ray passes it (no lane: 0xFFFFFFFF)
+                    unsigned k0 = a0 ? wave_umin(p0 ? __float_as_uint(t0) : 0xFFFFFFFFu) : 0xFFFFFFFFu;
+                    unsigned k1 = a1 ? wave_umin(p1 ? __float_as_uint(t1) : 0xFFFFFFFFu) : 0xFFFFFFFFu;
+                    unsigned k2 = a2 ? wave_umin(p2 ? __float_as_uint(t2) : 0xFFFFFFFFu) : 0xFFFFFFFFu;
+                    unsigned k3 = a3 ? wave_umin(p3 ? __float_as_uint(t3) : 0xFFFFFFFFu) : 0xFFFFFFFFu;
+                    auto order = [](unsigned &ka, unsigned &ra, unsigned &kb, unsigned &rb) {
+                        const bool sw = kb < ka;
+                        const unsigned kl = sw ? kb : ka, kh = sw ? ka : kb, rl = sw ? rb : ra, rh = sw ? ra : rb;
+                        ka = kl; kb = kh; ra = rl; rb = rh;
+                    };
+                    order(k0, r0, k1, r1);
+                    order(k2, r2, k3, r3);
+                    order(k0, r0, k2, r2);
+                    order(k1, r1, k3, r3);
+                    order(k1, r1, k2, r2);
+                    auto push = [&](unsigned r, unsigned key) {
+                        if(sp < PACKET_STACK) {
+                            if((int)lane == sp) {  // (one select each: lane sp takes the entry)
+                                st_ref = (int)r;
+                                st_key = (int)key;
+                            }
+                            ++sp;
+                        } else {
+                            *sc.error_flag = 1u;
+                        }
+                    };
                     if(k3 != 0xFFFFFFFFu) push(r3, k3);
                     if(k2 != 0xFFFFFFFFu) push(r2, k2);
                     if(k1 != 0xFFFFFFFFu) push(r1, k1);
