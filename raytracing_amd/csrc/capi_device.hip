@@ -137,6 +137,19 @@ struct pt_pass {
     int n_lanes = 3;
     int next_lane = 0;
     int batch_reserve = 1;  // pt_pass_reserve_batch: samples per draw that pt_pass_prepare sizes the path state for
+    // Camera rays over the flattened tree: one ray per lane (kind 0) or one tile per wave (kind 1, trace_packet.h).  Which
+    // is faster depends on how many triangles a tile of 8 x 8 pixels sees (few: the tile's rays share their walk; many:
+    // every lane pays for the union of 64 walks), so the pass times the first launch of each kind (events on the draw's
+    // stream, read when they have completed, no wait) and keeps the faster one until the flattened tree is rebuilt.
+    // Results do not depend on the choice.
+    struct PrimaryTuner {
+        hipEvent_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
+        size_t slots[2] = {0, 0};
+        bool pending[2] = {false, false};
+        double ms_per_slot[2] = {0.0, 0.0};
+        int decided = -1;
+        uint64_t flat_build = 0;  // the flattened tree the measurements belong to
+    } primary_tuner;
     hipEvent_t last_gbuf = nullptr, last_fin = nullptr;  // of the previous draw; null before the first
     hipStream_t cur_stream = nullptr;                    // stream the ScopedTimer records on
     DeviceArray d_counters, d_stats, d_err;  // d_err: traversal counters of RT_TRACE_STATS builds (bytes 16..47)
@@ -990,6 +1003,8 @@ int pt_pass_destroy(pt_pass *p) {
     if(p->d_accum_group) (void)hipFree(p->d_accum_group);
     if(p->d_lastwrite_group) (void)hipFree(p->d_lastwrite_group);
     collect_profile(p);
+    for(hipEvent_t e : {p->primary_tuner.a[0], p->primary_tuner.a[1], p->primary_tuner.b[0], p->primary_tuner.b[1]})
+        if(e) (void)hipEventDestroy(e);
     for(hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
     for(pt_pass::Lane &l : p->lanes) release_lane(l);
     DeviceArray *arrs[] = {&p->d_mesh_buf, &p->d_scene_buf, &p->d_flat_buf, &p->d_redo_isect,
@@ -1153,8 +1168,46 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     const bool fused_primary = ordered && !raster_first;
     // camera rays of a tile walk the flattened tree together when its deepest walk fits the wave's stack (RTA_PRIMARY_PACKETS=0:
     // one ray per lane, a tuning aid)
-    static const bool packets_wanted = !(getenv("RTA_PRIMARY_PACKETS") && atoi(getenv("RTA_PRIMARY_PACKETS")) == 0);
-    const bool packets = packets_wanted && fsc.flat_buf != nullptr && p->flat.max_stack + 2 <= packet_stack_entries();
+    static const int packets_forced = getenv("RTA_PRIMARY_PACKETS") ? atoi(getenv("RTA_PRIMARY_PACKETS")) : -1;  // 0 / 1: a tuning aid
+    const bool packets_possible = fused_primary && fsc.flat_buf != nullptr && p->flat.max_stack + 2 <= packet_stack_entries();
+    bool packets = packets_possible && packets_forced != 0;
+    int tuner_kind = -1;  // >= 0: this draw's primary launch is timed as a measurement of that kind
+    if(packets_possible && packets_forced < 0) {
+        pt_pass::PrimaryTuner &tu = p->primary_tuner;
+        if(tu.flat_build != p->flat_builds) {  // another tree: measure again
+            tu.flat_build = p->flat_builds;
+            tu.decided = -1;
+            tu.pending[0] = tu.pending[1] = false;
+            tu.ms_per_slot[0] = tu.ms_per_slot[1] = 0.0;
+        }
+        for(int k = 0; k < 2; k++)
+            if(tu.pending[k] && hipEventQuery(tu.b[k]) == hipSuccess) {
+                float ms = 0.0f;
+                if(hipEventElapsedTime(&ms, tu.a[k], tu.b[k]) == hipSuccess && tu.slots[k]) tu.ms_per_slot[k] = (double)ms / (double)tu.slots[k];
+                tu.pending[k] = false;
+            }
+        if(tu.decided < 0 && tu.ms_per_slot[0] > 0.0 && tu.ms_per_slot[1] > 0.0) {
+            // (launches of different sizes do not compare: a thin one waits for its slowest walk, a fat one fills the chip)
+            if(tu.slots[0] == tu.slots[1]) tu.decided = tu.ms_per_slot[1] <= tu.ms_per_slot[0] ? 1 : 0;
+            else tu.ms_per_slot[tu.slots[0] == npix ? 1 : 0] = 0.0;  // keep the one that was taken at this draw's size
+        }
+        if(tu.decided >= 0) {
+            packets = tu.decided == 1;
+        } else {
+            // not known yet: measure the kind that has neither a figure nor a launch under way (packets first)
+            int k = -1;
+            for(int c : {1, 0})
+                if(k < 0 && tu.ms_per_slot[c] == 0.0 && !tu.pending[c]) k = c;
+            if(k >= 0 && !p->profiling) {
+                for(hipEvent_t *e : {&tu.a[k], &tu.b[k]})
+                    if(!*e) HIP_TRY(hipEventCreate(e));
+                tuner_kind = k;
+                packets = k == 1;
+            } else {
+                packets = true;  // (both measurements under way, or the per-kernel profile is being taken: the likelier one)
+            }
+        }
+    }
     if(!fused_primary) {
         ScopedTimer t(p, K_OTHER);
         launch_generate(s, dp);
@@ -1173,8 +1226,15 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     auto extend = [&](int dep, const unsigned *q) {
         ScopedTimer t(p, K_EXTEND);
         if(ordered) {
-            if(dep == 0 && fused_primary)
+            if(dep == 0 && fused_primary) {
+                if(tuner_kind >= 0) (void)hipEventRecord(p->primary_tuner.a[tuner_kind], s);
                 launch_primary_fast(s, fsc, grid, dp, cnt + CNT_NEXT + 2 * dep, qr, cnt + CNT_REDO + dep, packets);
+                if(tuner_kind >= 0) {
+                    (void)hipEventRecord(p->primary_tuner.b[tuner_kind], s);
+                    p->primary_tuner.slots[tuner_kind] = npix;
+                    p->primary_tuner.pending[tuner_kind] = true;
+                }
+            }
             else
                 launch_extend_fast(s, fsc, grid, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, qr,
                                    cnt + CNT_REDO + dep);

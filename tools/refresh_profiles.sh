@@ -1,8 +1,12 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+r=${1:-r03}
 bash tools/profile_all.sh
-bash tools/run_pmc.sh gpurun_out/pmc_casa_pt --steps 16 --warmup 2 --pipeline 1 --tail 0
+# counter passes of the launches the roofline leg of bench.py times: the timed region's batches, one draw in flight, no tail launch
+bash tools/run_pmc.sh gpurun_out/pmc_casa_pt --steps 32 --warmup 16 --pipeline 1 --tail 0 --batch 16
 bash tools/run_pmc.sh gpurun_out/pmc_casa_isect --workload casa_isect --steps 4 --warmup 1
-bash tools/run_pmc.sh gpurun_out/pmc_synth_pt --workload synth_pt --steps 4 --warmup 1 --pipeline 1 --tail 0
-for w in casa_pt casa_isect synth_pt; do python3 tools/summarize_pmc.py gpurun_out/pmc_$w --json gpurun_out/r02_pmc_$w.json > gpurun_out/r02_pmc_$w.txt; done
+bash tools/run_pmc.sh gpurun_out/pmc_synth_pt --workload synth_pt --steps 12 --warmup 6 --pipeline 1 --tail 0 --batch 6
+python3 tools/summarize_pmc.py gpurun_out/pmc_casa_pt --json gpurun_out/${r}_pmc_casa_pt.json --samples 48 > gpurun_out/${r}_pmc_casa_pt.txt
+python3 tools/summarize_pmc.py gpurun_out/pmc_casa_isect --json gpurun_out/${r}_pmc_casa_isect.json > gpurun_out/${r}_pmc_casa_isect.txt
+python3 tools/summarize_pmc.py gpurun_out/pmc_synth_pt --json gpurun_out/${r}_pmc_synth_pt.json --samples 18 > gpurun_out/${r}_pmc_synth_pt.txt

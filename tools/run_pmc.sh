@@ -10,7 +10,7 @@ out=$1; shift
 mkdir -p "$out"
 export TMPDIR=/tmp
 # bench.py asks for 16 hardware queues, but under rocprofv3 the HIP runtime starts before bench.py runs
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
+
 groups=(
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
   "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
