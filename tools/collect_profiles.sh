@@ -8,7 +8,7 @@ if [ "$what" = pmc ]; then
     cp gpurun_out/${r}_pmc_$w.json profiles/${r}_pmc_$w.json && cp gpurun_out/${r}_pmc_$w.txt profiles/${r}_pmc_$w.txt || exit 1
   done
   for w in casa_pt casa_pt_batch_serial casa_pt_serial casa_isect synth_pt; do
-    f=$(ls gpurun_out/prof_$w/*/*kernel_stats.csv 2>/dev/null | head -1)
+    f=$(ls -t gpurun_out/prof_$w/*/*kernel_stats.csv 2>/dev/null | head -1)   # the newest: earlier runs leave theirs behind
     [ -n "$f" ] && cp "$f" profiles/${r}_${w}_kernel_stats.csv
     cp gpurun_out/prof_$w.json profiles/${r}_bench_${w}_under_rocprof.json
   done
