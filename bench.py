@@ -529,6 +529,13 @@ def main():
                             out["hbm_bytes_per_sample_measured"] = pmc["_meta"]["hbm_bytes_per_sample"]
                         rf["traffic"] = tot / max(n_launch, 1)
                         rf["traffic_source"] = "profiles/" + os.path.basename(pmc_file)
+                        pmc_batch = pmc.get("_meta", {}).get("samples_per_draw")
+                        if wl != "casa_isect" and pmc_batch and pmc_batch != max(args.batch, 1):
+                            # the counter passes drew other batches than this run: a launch carries the rays of `batch` samples
+                            # and its bytes follow (path state and queue entries per ray; the tree stays in the caches)
+                            rf["traffic"] *= max(args.batch, 1) / float(pmc_batch)
+                            rf["traffic_scaled"] = ("counter passes drew %d samples per launch, this run %d: bytes per launch scaled by "
+                                                    "that ratio" % (pmc_batch, max(args.batch, 1)))
                         rf["algorithmic_bytes_per_launch"] = rf["rays_per_launch"] * b_ray
                         # the physical figure: bytes really moved per launch over this run's launch time
                         rf["hbm_gbs_measured"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9

@@ -7,6 +7,6 @@ bash tools/profile_all.sh
 bash tools/run_pmc.sh gpurun_out/pmc_casa_pt --steps 32 --warmup 16 --pipeline 1 --tail 0 --batch 16
 bash tools/run_pmc.sh gpurun_out/pmc_casa_isect --workload casa_isect --steps 4 --warmup 1
 bash tools/run_pmc.sh gpurun_out/pmc_synth_pt --workload synth_pt --steps 12 --warmup 6 --pipeline 1 --tail 0 --batch 6
-python3 tools/summarize_pmc.py gpurun_out/pmc_casa_pt --json gpurun_out/${r}_pmc_casa_pt.json --samples 48 > gpurun_out/${r}_pmc_casa_pt.txt
+python3 tools/summarize_pmc.py gpurun_out/pmc_casa_pt --json gpurun_out/${r}_pmc_casa_pt.json --samples 48 --batch 16 > gpurun_out/${r}_pmc_casa_pt.txt
 python3 tools/summarize_pmc.py gpurun_out/pmc_casa_isect --json gpurun_out/${r}_pmc_casa_isect.json > gpurun_out/${r}_pmc_casa_isect.txt
-python3 tools/summarize_pmc.py gpurun_out/pmc_synth_pt --json gpurun_out/${r}_pmc_synth_pt.json --samples 18 > gpurun_out/${r}_pmc_synth_pt.txt
+python3 tools/summarize_pmc.py gpurun_out/pmc_synth_pt --json gpurun_out/${r}_pmc_synth_pt.json --samples 18 --batch 6 > gpurun_out/${r}_pmc_synth_pt.txt

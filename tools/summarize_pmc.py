@@ -1,6 +1,7 @@
 """Sums rocprofv3 --pmc counter CSVs per kernel name.
-Usage: summarize_pmc.py <dir> [kernel substring] [--json out.json] [--samples N]
-(--samples: how many samples per pixel the profiled run drew, warm-up included; stored so that bytes per sample can be quoted)
+Usage: summarize_pmc.py <dir> [kernel substring] [--json out.json] [--samples N] [--batch B]
+(--samples: how many samples per pixel the profiled run drew, warm-up included; stored so that bytes per sample can be quoted;
+ --batch: how many samples each draw of the profiled run carried, i.e. how fat its launches were; stored for the same reason)
 With --json, also writes {kernel: {counter: {"total":, "launches":}}} plus HBM bytes per launch
 (FETCH_SIZE and WRITE_SIZE are in KiB; for this library's access pattern -- 64-byte records
 gathered with four 16-byte loads per lane -- tools/calib/fetch_calib.hip measured FETCH_SIZE
@@ -11,9 +12,17 @@ import json
 import sys
 from collections import defaultdict
 
-samples = int(sys.argv[sys.argv.index("--samples") + 1]) if "--samples" in sys.argv else None
-if samples is not None:
-    del sys.argv[sys.argv.index("--samples"):sys.argv.index("--samples") + 2]
+def int_flag(name):
+    if name not in sys.argv:
+        return None
+    k = sys.argv.index(name)
+    v = int(sys.argv[k + 1])
+    del sys.argv[k:k + 2]
+    return v
+
+
+samples = int_flag("--samples")
+batch = int_flag("--batch")
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 d = args[0]
 sub = args[1] if len(args) > 1 and not args[1].endswith(".json") else ""
@@ -47,6 +56,8 @@ if jout:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from raytracing_amd.build import kernel_sources_digest
     out["_meta"] = {"kernel_sources_sha256": kernel_sources_digest()}
+    if batch:
+        out["_meta"]["samples_per_draw"] = batch
     if samples:
         # every kernel of the run, the library's and the runtime's fills / copies: HBM bytes per sample per pixel-frame
         fetch = sum(tot[k].get("FETCH_SIZE", 0.0) for k in tot) * 1024.0
