@@ -25,6 +25,7 @@ constexpr int CNT_REDO = 280;       // [280, 350): rays the ordered extend hande
 constexpr int CNT_NEXT_REDO = 350;  // [350, 420): next-ray counters of those launches
 constexpr int CNT_INTERSECT = 420;  // next-ray, redo count, next-ray of the redo launch
 constexpr int CNT_TAIL = 424;       // batch counter of the tail launch
+constexpr int CNT_TUNE = 425;       // next-ray counter of the second primary launch of a draw that times both kinds
 constexpr int CNT_SHADOW_REDO = 432;       // [432, 502): occlusion queries the ordered traversal left undecided, per vertex
 constexpr int CNT_NEXT_SHADOW_REDO = 502;  // [502, 572): next-ray counters of the launches that trace those
 constexpr int CNT_TOTAL = 572;
@@ -139,13 +140,17 @@ struct pt_pass {
     int batch_reserve = 1;  // pt_pass_reserve_batch: samples per draw that pt_pass_prepare sizes the path state for
     // Camera rays over the flattened tree: one ray per lane (kind 0) or one tile per wave (kind 1, trace_packet.h).  Which
     // is faster depends on how many triangles a tile of 8 x 8 pixels sees (few: the tile's rays share their walk; many:
-    // every lane pays for the union of 64 walks), so the pass times the first launch of each kind (events on the draw's
-    // stream, read when they have completed, no wait) and keeps the faster one until the flattened tree is rebuilt.
+    // every lane pays for the union of 64 walks), so the pass times a launch of each kind (events on the draw's
+    // stream, read when they have completed, no wait) and keeps the faster one until the flattened tree is rebuilt: on the
+    // first draw that carries two samples or more, one half of the samples goes through each kind (the same image, so the
+    // two figures compare); draws of one sample are timed one kind per draw and compared when their sizes are equal.
     // Results do not depend on the choice.
     struct PrimaryTuner {
         hipEvent_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
         size_t slots[2] = {0, 0};
         bool pending[2] = {false, false};
+        bool halves[2] = {false, false};  // the figure is of one half of a draw whose other half went through the other kind
+        int draws_seen = 0;               // draws over this tree so far (the first one is not timed: caches and code are cold)
         double ms_per_slot[2] = {0.0, 0.0};
         int decided = -1;
         uint64_t flat_build = 0;  // the flattened tree the measurements belong to
@@ -1171,7 +1176,8 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     static const int packets_forced = getenv("RTA_PRIMARY_PACKETS") ? atoi(getenv("RTA_PRIMARY_PACKETS")) : -1;  // 0 / 1: a tuning aid
     const bool packets_possible = fused_primary && fsc.flat_buf != nullptr && p->flat.max_stack + 2 <= packet_stack_entries();
     bool packets = packets_possible && packets_forced != 0;
-    int tuner_kind = -1;  // >= 0: this draw's primary launch is timed as a measurement of that kind
+    int tuner_kind = -1;       // >= 0: this draw's primary launch is timed as a measurement of that kind
+    bool tuner_halves = false;  // this draw's samples go half through each kind, both timed
     if(packets_possible && packets_forced < 0) {
         pt_pass::PrimaryTuner &tu = p->primary_tuner;
         if(tu.flat_build != p->flat_builds) {  // another tree: measure again
@@ -1179,7 +1185,9 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
             tu.decided = -1;
             tu.pending[0] = tu.pending[1] = false;
             tu.ms_per_slot[0] = tu.ms_per_slot[1] = 0.0;
+            tu.draws_seen = 0;
         }
+        const bool cold = tu.draws_seen++ == 0;
         for(int k = 0; k < 2; k++)
             if(tu.pending[k] && hipEventQuery(tu.b[k]) == hipSuccess) {
                 float ms = 0.0f;
@@ -1188,24 +1196,30 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
             }
         if(tu.decided < 0 && tu.ms_per_slot[0] > 0.0 && tu.ms_per_slot[1] > 0.0) {
             // (launches of different sizes do not compare: a thin one waits for its slowest walk, a fat one fills the chip)
-            if(tu.slots[0] == tu.slots[1]) tu.decided = tu.ms_per_slot[1] <= tu.ms_per_slot[0] ? 1 : 0;
+            if((tu.halves[0] && tu.halves[1]) || tu.slots[0] == tu.slots[1]) tu.decided = tu.ms_per_slot[1] <= tu.ms_per_slot[0] ? 1 : 0;
             else tu.ms_per_slot[tu.slots[0] == npix ? 1 : 0] = 0.0;  // keep the one that was taken at this draw's size
+            static const bool log = getenv("RTA_TUNER_LOG") != nullptr;  // (a tuning aid)
+            if(log && tu.decided >= 0)
+                fprintf(stderr, "primary launch: %.3f ns per slot one ray per lane (%zu slots), %.3f as tiles (%zu slots): %s\n",
+                        tu.ms_per_slot[0] * 1e6, tu.slots[0], tu.ms_per_slot[1] * 1e6, tu.slots[1], tu.decided ? "tiles" : "per lane");
         }
         if(tu.decided >= 0) {
             packets = tu.decided == 1;
-        } else {
-            // not known yet: measure the kind that has neither a figure nor a launch under way (packets first)
-            int k = -1;
-            for(int c : {1, 0})
-                if(k < 0 && tu.ms_per_slot[c] == 0.0 && !tu.pending[c]) k = c;
-            if(k >= 0 && !p->profiling) {
+        } else if(cold || p->profiling || tu.pending[0] || tu.pending[1]) {
+            packets = true;  // (not to be timed, a measurement is under way, or the per-kernel profile is being taken: the likelier kind)
+        } else if(n >= 2) {
+            for(int k = 0; k < 2; k++)
                 for(hipEvent_t *e : {&tu.a[k], &tu.b[k]})
                     if(!*e) HIP_TRY(hipEventCreate(e));
-                tuner_kind = k;
-                packets = k == 1;
-            } else {
-                packets = true;  // (both measurements under way, or the per-kernel profile is being taken: the likelier one)
-            }
+            tuner_halves = true;
+            if(getenv("RTA_TUNER_LOG")) fprintf(stderr, "primary launch: timing both kinds on a draw of %d samples\n", n);
+        } else {
+            // one sample per draw: the kind that has no figure yet (packets first)
+            const int k = tu.ms_per_slot[1] == 0.0 ? 1 : 0;
+            for(hipEvent_t *e : {&tu.a[k], &tu.b[k]})
+                if(!*e) HIP_TRY(hipEventCreate(e));
+            tuner_kind = k;
+            packets = k == 1;
         }
     }
     if(!fused_primary) {
@@ -1226,13 +1240,28 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     auto extend = [&](int dep, const unsigned *q) {
         ScopedTimer t(p, K_EXTEND);
         if(ordered) {
-            if(dep == 0 && fused_primary) {
+            if(dep == 0 && fused_primary && tuner_halves) {
+                // the first samples as packets, the others one ray per lane, each launch between two events
+                pt_pass::PrimaryTuner &tu = p->primary_tuner;
+                const unsigned first = (unsigned)(n / 2) * (unsigned)npix1, rest = (unsigned)npix - first;
+                (void)hipEventRecord(tu.a[1], s);
+                launch_primary_fast(s, fsc, grid, dp, cnt + CNT_NEXT, qr, cnt + CNT_REDO, true, 0u, first, true);
+                (void)hipEventRecord(tu.b[1], s);
+                (void)hipEventRecord(tu.a[0], s);
+                launch_primary_fast(s, fsc, grid, dp, cnt + CNT_TUNE, qr, cnt + CNT_REDO, false, first, rest, false);
+                (void)hipEventRecord(tu.b[0], s);
+                tu.slots[1] = first;
+                tu.slots[0] = rest;
+                tu.pending[0] = tu.pending[1] = true;
+                tu.halves[0] = tu.halves[1] = true;
+            } else if(dep == 0 && fused_primary) {
                 if(tuner_kind >= 0) (void)hipEventRecord(p->primary_tuner.a[tuner_kind], s);
-                launch_primary_fast(s, fsc, grid, dp, cnt + CNT_NEXT + 2 * dep, qr, cnt + CNT_REDO + dep, packets);
+                launch_primary_fast(s, fsc, grid, dp, cnt + CNT_NEXT + 2 * dep, qr, cnt + CNT_REDO + dep, packets, 0u, (unsigned)npix, true);
                 if(tuner_kind >= 0) {
                     (void)hipEventRecord(p->primary_tuner.b[tuner_kind], s);
                     p->primary_tuner.slots[tuner_kind] = npix;
                     p->primary_tuner.pending[tuner_kind] = true;
+                    p->primary_tuner.halves[tuner_kind] = false;
                 }
             }
             else
@@ -1244,7 +1273,23 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
             launch_extend(s, sc, grid, q, cnt + CNT_QUEUE + dep, dp.rays, dp.hits, cnt + CNT_NEXT + 2 * dep, false);
         }
     };
-    if(!raster_first) extend(0, q_in);  // with RasterizaionFor1st the first hit comes from the raster images
+    // Camera rays walked as packets and vertex 0 shaded in ONE launch (trace_kernels.hip), when the first hit is a plain
+    // traced one and each stage need not be timed apart; the slots that launch leaves to the reference-order pass are
+    // traced by it and shaded by a small launch over their list.  RTA_FUSED_PRIMARY=0: two launches, a tuning aid.
+    static const bool fusion_off = getenv("RTA_FUSED_PRIMARY") && atoi(getenv("RTA_FUSED_PRIMARY")) == 0;
+    const bool fuse_first = !fusion_off && fused_primary && packets && tuner_kind < 0 && !tuner_halves && !p->profiling && !dp.raster_outputs &&
+                            tail_from != 0 && p->material_grouping <= 0;
+    if(fuse_first) {
+        // (this launch writes the last-write outputs: after the previous draw's)
+        if(p->last_gbuf && p->last_gbuf != L.gbuf) HIP_TRY(hipStreamWaitEvent(s, p->last_gbuf, 0));
+        launch_primary_shade_packets(s, fsc, grid, dp, cnt + CNT_NEXT, qr, cnt + CNT_REDO, qa, cnt + CNT_QUEUE + 1, qs, cnt + CNT_SHADOW);
+        launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO, dp.rays, dp.hits, cnt + CNT_NEXT_REDO, true);
+        launch_shade(s, dp, 0, qr, cnt + CNT_REDO, qa, cnt + CNT_QUEUE + 1, qs, cnt + CNT_SHADOW, false, false, true);
+        HIP_TRY(hipEventRecord(L.gbuf, s));
+        p->last_gbuf = L.gbuf;
+    } else if(!raster_first) {
+        extend(0, q_in);  // with RasterizaionFor1st the first hit comes from the raster images
+    }
     for(int dep = 0; dep <= P.MAX_DEPTH; dep++) {
         if(dep == tail_from) {
             // few paths are left: one launch carries them through all their remaining vertices
@@ -1257,8 +1302,8 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
         }
         unsigned *q_out = (dep & 1) ? qb : qa;
         // shading the first vertex writes the last-write outputs: after the previous draw's
-        if(dep == 0 && p->last_gbuf && p->last_gbuf != L.gbuf) HIP_TRY(hipStreamWaitEvent(s, p->last_gbuf, 0));
-        {
+        if(dep == 0 && !fuse_first && p->last_gbuf && p->last_gbuf != L.gbuf) HIP_TRY(hipStreamWaitEvent(s, p->last_gbuf, 0));
+        if(!(dep == 0 && fuse_first)) {
             ScopedTimer t(p, K_SHADE);
             // The library's choice, for a draw that is alone on the device: from vertex 1 on, every block moves the
             // paths that escaped behind the ones that hit something (at vertex 0 the sky fills whole tiles: nothing to
@@ -1271,7 +1316,7 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
             const bool group = by_material || (p->material_grouping < 0 && dep >= 1 && alone);
             launch_shade(s, dp, dep, q_in, cnt + CNT_QUEUE + dep, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, group, by_material);
         }
-        if(dep == 0) {
+        if(dep == 0 && !fuse_first) {
             HIP_TRY(hipEventRecord(L.gbuf, s));
             p->last_gbuf = L.gbuf;
         }

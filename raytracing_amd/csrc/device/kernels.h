@@ -131,17 +131,29 @@ void launch_generate(hipStream_t s, const DrawParams &dp);
 // generate + the ordered extend of vertex 0 in one launch (camera rays made where they are traced)
 // packets: over the flattened tree, one wave per tile of 64 slots walking one node sequence (trace_packet.h); the tree's
 // deepest walk must fit packet_stack_entries() deferred nodes
+// base, count: the slots of the draw this launch covers (multiples of 64; the whole draw: 0, dp.npix); books: it keeps the
+// draw's books (one launch of a draw does)
 void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter, unsigned *redo,
-                         unsigned *redo_count, bool packets);
+                         unsigned *redo_count, bool packets, unsigned base, unsigned count, bool books);
 int packet_stack_entries();
+// the packet form of launch_primary_fast and launch_shade for vertex 0 in one kernel (plain traced first hits only: no
+// raster images in play): a wave shades the pixels of a tile where its walk ends.  Slots it cannot decide are stored and
+// listed in redo as launch_primary_fast does; they want launch_extend(second_pass) and then launch_shade over that list
+// with `listed_only` set.
+void launch_primary_shade_packets(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter,
+                                  unsigned *redo, unsigned *redo_count, unsigned *queue_out, unsigned *count_out,
+                                  unsigned *shadow_queue, unsigned *shadow_count);
 // shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to
 // queue_out and paths with pending light samples to shadow_queue.
 // group: every block first sorts its 256 paths into two groups, so that at most one of its four waves runs the code
 // of both: paths that escaped (a sky lookup, shader/pathtracing.glsl:569-577) behind those that hit something, or,
 // with group_materials, dielectrics behind conductors (the reference dispatches per fragment,
 // shader/materials/materials.glsl:82-111).
+// listed_only: the launch shades the few slots of vertex 0 that launch_primary_shade_packets left to the reference-order
+// pass (queue_in is that list); the rays of the vertex have been counted by that launch.
 void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,
-                  unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group, bool group_materials);
+                  unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group, bool group_materials,
+                  bool listed_only = false);
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,
                          const unsigned *shadow_count);
 void launch_finalize(hipStream_t s, const DrawParams &dp);

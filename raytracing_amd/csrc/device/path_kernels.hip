@@ -72,7 +72,7 @@ template <int RASTER, bool GROUP, bool FIRST>
 __global__ __launch_bounds__(GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES, SHADE_WAVES))) void shade_kernel(DrawParams dp, int dep, const unsigned *queue_in,
                                                             const unsigned *count_in, unsigned *queue_out,
                                                             unsigned *count_out, unsigned *shadow_queue,
-                                                            unsigned *shadow_count, bool group_materials) {
+                                                            unsigned *shadow_count, bool group_materials, bool listed_only) {
     constexpr int BLOCK = GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK;
     __shared__ __align__(16) unsigned s_V[SOBOL_NIBBLE_WORDS];
     __shared__ unsigned s_null;  // light samples of this block that needed no occlusion query
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK) __attribut
 
     if(blockIdx.x == 0 && threadIdx.x == 0) {
         // (with RasterizaionFor1st the first vertex comes from images: no rays were traced for it)
-        if(RASTER != 1) atomicAdd(&dp.stats[1], FIRST ? (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch : (unsigned long long)n);
+        if(RASTER != 1 && !listed_only) atomicAdd(&dp.stats[1], FIRST ? (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch : (unsigned long long)n);
         if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
     }
 
@@ -301,23 +301,24 @@ void launch_generate(hipStream_t s, const DrawParams &dp) {
 }
 
 void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,
-                  unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group, bool group_materials) {
-    const dim3 grid(shade_grid(dp.npix)), block(SHADE_BLOCK);
+                  unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group, bool group_materials,
+                  bool listed_only) {
+    const dim3 grid(shade_grid(listed_only ? 4096 : dp.npix)), block(SHADE_BLOCK);
     if(dep == 0 && dp.p.RasterizaionFor1st != 0)
-        hipLaunchKernelGGL((shade_kernel<1, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
+        hipLaunchKernelGGL((shade_kernel<1, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, listed_only);
     else if(dep == 0 && dp.raster_outputs)
-        hipLaunchKernelGGL((shade_kernel<2, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
+        hipLaunchKernelGGL((shade_kernel<2, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, listed_only);
     else if(group) {
         int b = (dp.npix + SHADE_GROUP_BLOCK - 1) / SHADE_GROUP_BLOCK;
         b = b < 1 ? 1 : (b > 4096 ? 4096 : b);
         if(dep == 0)
-            hipLaunchKernelGGL((shade_kernel<0, true, true>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials);
+            hipLaunchKernelGGL((shade_kernel<0, true, true>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials, listed_only);
         else
-            hipLaunchKernelGGL((shade_kernel<0, true, false>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials);
+            hipLaunchKernelGGL((shade_kernel<0, true, false>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials, listed_only);
     } else if(dep == 0)
-        hipLaunchKernelGGL((shade_kernel<0, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
+        hipLaunchKernelGGL((shade_kernel<0, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, listed_only);
     else
-        hipLaunchKernelGGL((shade_kernel<0, false, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false);
+        hipLaunchKernelGGL((shade_kernel<0, false, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, listed_only);
 }
 
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,

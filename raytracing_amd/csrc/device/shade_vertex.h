@@ -75,9 +75,11 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 //      depth output is the raster depth and the albedo is looked up through the raster instance index, as there.
 // FIRST: dep == 0, known when the kernel is compiled: the launch of vertex 0 carries none of the code of later vertices
 // (throughput update, escape to the sky) and the launches of later vertices none of the first-hit outputs.
+// given: the closest hit of the slot's ray when the caller holds it in registers (the launch that traces the camera rays
+// and shades their hits in one go); null: it is read from dp.hits[i].
 template <int RASTER, bool FIRST>
 __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsigned i, const unsigned *s_T, bool &continues,
-                                             bool &has_shadow, unsigned &null_shadow) {
+                                             bool &has_shadow, unsigned &null_shadow, const LaneHit *given = nullptr) {
     continues = false;
     has_shadow = false;
     null_shadow = 0u;
@@ -123,6 +125,11 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
         g_uvy = guv.y;
         // an index that names no instance is treated as "not covered" (out of bounds in the reference)
         exist = hit_t <= 100000.0f && hit_inst >= 0 && hit_inst < dp.n_instances;
+    } else if(given) {
+        hit_t = given->t; hit_u = given->u; hit_v = given->v;
+        hit_tri = given->tri;
+        hit_inst = given->inst;
+        exist = hit_tri >= 0;
     } else {
         const float4 *hp = reinterpret_cast<const float4 *>(dp.hits + i);
         const float4 h0 = hp[0], h1 = hp[1];

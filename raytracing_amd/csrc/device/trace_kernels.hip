@@ -150,9 +150,10 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_fast_kernel(Fas
 // all rays first and this one reading them back.
 struct PrimarySource {
     const DrawParams &dp;
+    unsigned base;  // work item i is slot base + i (a launch may cover a range of the draw's slots)
     __device__ bool load(unsigned i, float o[3], float d[3], bool &any_hit) const {
         unsigned px, py, k;
-        if(!state_pixel(dp, i, px, py, k)) return false;  // a slot of an edge tile that names no pixel: nobody reads it
+        if(!state_pixel(dp, base + i, px, py, k)) return false;  // a slot of an edge tile that names no pixel: nobody reads it
         V3 ro, rd;
         camera_ray(dp.p, dp.samples[k].jitter[0], dp.samples[k].jitter[1], dp.tan_half_fov, px, py, ro, rd);
         // (nothing of the path state is stored: the launch that shades vertex 0 makes the same ray again and knows
@@ -168,7 +169,9 @@ struct PrimarySource {
 struct PrimarySinkFast {
     const DrawParams &dp;
     unsigned *redo, *redo_count;
-    __device__ void store(unsigned i, const LaneHit &h, bool ambiguous) const {
+    unsigned base;  // as in PrimarySource
+    __device__ void store(unsigned item, const LaneHit &h, bool ambiguous) const {
+        const unsigned i = base + item;
         write_path_hit(dp.hits, i, h);  // (provisional for an ambiguous ray: bounds its second pass)
         if(ambiguous) {
             // the reference-order launch behind this one reads its rays from the path state: store this one
@@ -182,34 +185,139 @@ struct PrimarySinkFast {
             redo[atomicAdd(redo_count, 1u)] = i;
         }
     }
+    // (the form the walk of whole tiles calls, trace_packet.h: it names slots)
+    __device__ void tile(unsigned slot, bool pixel, const LaneHit &h, bool ambiguous) const {
+        if(pixel) store(slot - base, h, ambiguous);
+    }
+    __device__ void finish() const {}
 };
 
+// The slots [base, base + count) of the draw (all of them, or -- when the host times the two kinds of launch against
+// each other on one draw -- the samples of one half); books: this launch keeps the draw's books.
 template <int MODE>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_fast_kernel(FastScene sc, DrawParams dp, unsigned *next_counter,
-                                                                  unsigned *redo, unsigned *redo_count) {
+                                                                  unsigned *redo, unsigned *redo_count, unsigned base, unsigned count,
+                                                                  bool books) {
     __shared__ uint2 s_stack[FAST_LDS_STACK * FAST_BLOCK];
-    if(blockIdx.x == 0 && threadIdx.x == 0) {
+    if(books && blockIdx.x == 0 && threadIdx.x == 0) {
         // the books generate_kernel keeps (path_kernels.hip)
         atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch);
         atomicAdd(&dp.stats[3], (unsigned long long)dp.batch);
         dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
     }
-    PrimarySource src{dp};
-    PrimarySinkFast sink{dp, redo, redo_count};
-    trace_fast_any<MODE>(sc, src, sink, next_counter, (unsigned)dp.npix, s_stack);
+    PrimarySource src{dp, base};
+    PrimarySinkFast sink{dp, redo, redo_count, base};
+    trace_fast_any<MODE>(sc, src, sink, next_counter, count, s_stack);
 }
 
 // The same launch for a pass that walks the flattened tree: one wave per tile of 64 slots, all lanes on one node
 // sequence (trace_packet.h).  No LDS.
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_packet_kernel(FastScene sc, DrawParams dp, unsigned *next_counter,
-                                                                    unsigned *redo, unsigned *redo_count) {
-    if(blockIdx.x == 0 && threadIdx.x == 0) {
+                                                                    unsigned *redo, unsigned *redo_count, unsigned base, unsigned count,
+                                                                    bool books) {
+    if(books && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&dp.stats[0], (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch);
         atomicAdd(&dp.stats[3], (unsigned long long)dp.batch);
         dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
     }
-    PrimarySinkFast sink{dp, redo, redo_count};
-    trace_flat_packets(sc, dp, sink, next_counter, (unsigned)dp.npix);
+    PrimarySinkFast sink{dp, redo, redo_count, base};
+    trace_flat_packets(sc, dp, sink, next_counter, count, base);
+}
+
+// The packet launch and the shade launch of vertex 0 as ONE kernel.  The walk of a tile is bound by vector-ALU issue,
+// the shading of its 64 hits by memory (gathers of triangle, material, texel and sky records, the path state it
+// writes): as two launches each leaves the other resource idle; in one kernel the waves of a SIMD are at different
+// points -- some walking, some waiting for their gathers -- and the hardware overlaps them.  The hit record of vertex 0
+// stays in registers (32 bytes per pixel less each way).  A wave walks a tile, shades its pixels where the walk ends
+// (shade_vertex with the hit handed over), keeps what the pixels append to the two queues in LDS, and updates the queue
+// counters once per PRIMARY_SHADE_ROUND tiles (path_kernels.hip has the reason: the chip completes about ninety
+// same-word atomics per microsecond).  A ray the walk cannot decide is stored and listed as the packet launch does;
+// the reference-order launch behind this one traces it and a small shade launch over that list shades it.
+#ifndef RT_PRIMARY_SHADE_ROUND
+#define RT_PRIMARY_SHADE_ROUND 8
+#endif
+constexpr int PRIMARY_SHADE_ROUND = RT_PRIMARY_SHADE_ROUND;
+
+struct PrimaryShadeSink {
+    const DrawParams &dp;
+    unsigned *redo, *redo_count;
+    const unsigned *s_T;   // the Sobol table in LDS
+    unsigned *stage;       // this wave's PRIMARY_SHADE_ROUND x 64 words of LDS
+    unsigned *queue_out, *count_out, *shadow_queue, *shadow_count;
+    unsigned staged, cont_bits, shad_bits, null_count;
+
+    __device__ void tile(unsigned i, bool pixel, const LaneHit &h, bool ambiguous) {
+        const unsigned lane = threadIdx.x & 63u;
+        bool continues = false, has_shadow = false;
+        if(pixel) {
+            if(ambiguous) {
+                PrimarySinkFast{dp, redo, redo_count, 0u}.store(i, h, true);
+            } else {
+                unsigned null_shadow;
+                shade_vertex<0, true>(dp, 0, i, s_T, continues, has_shadow, null_shadow, &h);
+                null_count += null_shadow;
+            }
+        }
+        stage[staged * 64u + lane] = i;
+        cont_bits |= (continues ? 1u : 0u) << staged;
+        shad_bits |= (has_shadow ? 1u : 0u) << staged;
+        if(++staged == (unsigned)PRIMARY_SHADE_ROUND) flush();
+    }
+    __device__ void flush() {
+        const unsigned lane = threadIdx.x & 63u;
+        unsigned tot_c = 0u, tot_s = 0u;
+#pragma unroll 1
+        for(unsigned u = 0; u < staged; u++) {
+            tot_c += (unsigned)__popcll(__ballot((cont_bits >> u) & 1u));
+            tot_s += (unsigned)__popcll(__ballot((shad_bits >> u) & 1u));
+        }
+        unsigned base_c = 0u, base_s = 0u;
+        if(lane == 0u) {
+            if(tot_c) base_c = atomicAdd(count_out, tot_c);
+            if(tot_s) base_s = atomicAdd(shadow_count, tot_s);
+        }
+        base_c = __builtin_amdgcn_readfirstlane(base_c);
+        base_s = __builtin_amdgcn_readfirstlane(base_s);
+#pragma unroll 1
+        for(unsigned u = 0; u < staged; u++) {
+            const bool c = (cont_bits >> u) & 1u, sh = (shad_bits >> u) & 1u;
+            const unsigned long long m_c = __ballot(c), m_s = __ballot(sh);
+            const unsigned slot = (c || sh) ? stage[u * 64u + lane] : 0u;
+            if(c) queue_out[base_c + __builtin_amdgcn_mbcnt_hi((unsigned)(m_c >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_c, 0u))] = slot;
+            if(sh) shadow_queue[base_s + __builtin_amdgcn_mbcnt_hi((unsigned)(m_s >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_s, 0u))] = slot;
+            base_c += (unsigned)__popcll(m_c);
+            base_s += (unsigned)__popcll(m_s);
+        }
+        staged = 0u;
+        cont_bits = shad_bits = 0u;
+    }
+    __device__ void finish() {
+        if(staged) flush();
+    }
+};
+
+__global__ __launch_bounds__(FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void primary_shade_packet_kernel(
+    FastScene sc, DrawParams dp, unsigned *next_counter, unsigned *redo, unsigned *redo_count, unsigned *queue_out, unsigned *count_out,
+    unsigned *shadow_queue, unsigned *shadow_count) {
+    __shared__ __align__(16) unsigned s_V[SOBOL_NIBBLE_WORDS];
+    __shared__ unsigned s_stage[PRIMARY_SHADE_ROUND * FAST_BLOCK];
+    __shared__ unsigned s_null;
+    if(threadIdx.x == 0) s_null = 0u;
+    load_sobol_to_lds(s_V);
+    if(blockIdx.x == 0 && threadIdx.x == 0) {
+        // the books of the two launches this one stands for (generate / primary, and shade of vertex 0)
+        const unsigned long long rays = (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch;
+        atomicAdd(&dp.stats[0], rays);
+        atomicAdd(&dp.stats[3], (unsigned long long)dp.batch);
+        atomicAdd(&dp.stats[1], rays);
+        dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
+    }
+    PrimaryShadeSink sink{dp, redo, redo_count, s_V, s_stage + (threadIdx.x >> 6) * (PRIMARY_SHADE_ROUND * 64), queue_out, count_out,
+                          shadow_queue, shadow_count, 0u, 0u, 0u, 0u};
+    trace_flat_packets(sc, dp, sink, next_counter, (unsigned)dp.npix, 0u);
+    if(sink.null_count) atomicAdd(&s_null, sink.null_count);
+    __syncthreads();
+    if(threadIdx.x == 0 && s_null) atomicAdd(&dp.stats[5], (unsigned long long)s_null);
 }
 
 // ---- shadow ------------------------------------------------------------------------------
@@ -415,13 +523,21 @@ void launch_path_trace_fast(hipStream_t s, const FastScene &sc, int blocks, cons
 }
 
 void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter, unsigned *redo,
-                         unsigned *redo_count, bool packets) {
+                         unsigned *redo_count, bool packets, unsigned base, unsigned count, bool books) {
     if(packets && sc.flat_buf)
-        hipLaunchKernelGGL(primary_packet_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp, next_counter, redo, redo_count);
+        hipLaunchKernelGGL(primary_packet_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp, next_counter, redo, redo_count, base,
+                           count, books);
     else
         hipLaunchKernelGGL(RT_PICK_FAST(primary_fast_kernel), dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp,
-                           next_counter, redo, redo_count);
+                           next_counter, redo, redo_count, base, count, books);
 }
+void launch_primary_shade_packets(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter,
+                                  unsigned *redo, unsigned *redo_count, unsigned *queue_out, unsigned *count_out,
+                                  unsigned *shadow_queue, unsigned *shadow_count) {
+    hipLaunchKernelGGL(primary_shade_packet_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp, next_counter, redo, redo_count,
+                       queue_out, count_out, shadow_queue, shadow_count);
+}
+
 int packet_stack_entries() { return PACKET_STACK; }
 
 void launch_intersect(hipStream_t s, const TraceScene &sc, int blocks, const float *rays, unsigned n,

@@ -37,16 +37,20 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
 }
 __device__ __forceinline__ unsigned wave_umax(unsigned v) { return ~wave_umin(~v); }
 
-// Sink: void store(unsigned slot, const LaneHit &h, bool ambiguous), called for every slot that names a pixel.
+// Sink: void tile(unsigned slot, bool pixel, const LaneHit &h, bool ambiguous), called by ALL lanes of the wave at the end
+// of a tile's walk (pixel: the lane's slot names a pixel; the other arguments mean something only then), and
+// void finish(), called by all lanes when the wave has no tile left.
+// The launch covers the slots [slot_base, slot_base + n_slots) of the draw, both multiples of 64.
 template <class Sink>
 __device__ __forceinline__ void trace_flat_packets(const FastScene &sc, const DrawParams &dp, Sink &sink, unsigned *next_tile,
-                                                   unsigned n_slots) {
+                                                   unsigned n_slots, unsigned slot_base) {
     WaveRayFeed feed(n_slots);  // hands out whole tiles: batch sizes and n_slots are multiples of 64
     const unsigned lane = threadIdx.x & 63u;
     for(;;) {
         unsigned slot = 0;
         const bool got = feed.take(true, next_tile, n_slots, slot);
         if(!__any(got)) break;
+        slot += slot_base;
         // ---- this lane's camera ray (shader/pathtracing.glsl:604-608) and what trace_flat.h derives from a ray
         unsigned px = 0, py = 0, k = 0;
         const bool pixel = got && state_pixel(dp, slot, px, py, k);
@@ -239,16 +243,18 @@ __device__ __forceinline__ void trace_flat_packets(const FastScene &sc, const Dr
             }
         }
         // ---- the end of every ray of the tile (the decision trace_flat.h makes when a lane's stack runs empty)
+        bool ambiguous = false;
         if(pixel) {
             const bool odd = best_gate > best.t * 1.0005f + 4.0f * abs_slack;
-            const bool ambiguous = uncertain || (best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f));
+            ambiguous = uncertain || (best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f));
             if(ambiguous && odd) best.t = RT_INF;
             if(uncertain) {
                 best.t = RT_INF; best.tri = -1; best.inst = -1;
             }
-            sink.store(slot, best, ambiguous);
         }
+        sink.tile(slot, pixel, best, ambiguous);
     }
+    sink.finish();
 }
 
 }  // namespace rta

@@ -141,3 +141,42 @@ def test_batch_arguments_are_checked(gpu_ctx, casa, small_sky):
     gpu_ctx.synchronize()
     p.destroy()
     sb.release()
+
+
+@pytest.mark.parametrize("lights", [0, 2])
+def test_camera_rays_and_first_vertex_in_one_launch(gpu_ctx, casa, small_sky, oracle_mod, lights):
+    """With the scene laid out ahead of the first draw (pt_pass_prepare) the camera rays walk the flattened tree as tiles and
+    their hits are shaded in the same launch; with per-kernel profiling on, every stage is a launch of its own.  Both must
+    give the oracle's outputs and the same ray counts -- with analytic lights too (several shadow entries per vertex)."""
+    from raytracing_amd import device, scene
+    if lights:
+        sd = scene.synthetic_scene(20_000, seed=5, dielectric_fraction=0.3, lights=lights, textures=2, texture_size=64)
+        camera = scene.synthetic_camera()
+    else:
+        sd, camera = casa, scene.casa_camera()
+    w, h, depth = 136, 76, 4   # (edge tiles: 136 = 17 x 8, 76 = 9.5 x 8)
+    sb = device.SceneBuffers(gpu_ctx, sd, small_sky)
+    p = device.PathTracingPass(gpu_ctx, w, h)
+    p.bind_scene(sb)
+    if lights:
+        p.set_traversal(3)   # (its instances are rotated: the flattened tree is built only when asked for)
+    p.prepare()
+    prms = params_of(scene, sd, small_sky, camera, w, h, [1, 2, 3, 4, 5], depth)
+    osc = oracle_mod.OracleScene(sd, small_sky)
+    acc = None
+    for prm in prms:
+        acc, _ = osc.render(prm, acc)
+    p.stats(reset=True)
+    got, st = batched(p, prms, [5])
+    assert st["flat_leaves"] > 0
+    for k in acc:
+        assert words_equal(got[k], acc[k].reshape(got[k].shape)), ("one launch", k)
+    p.set_profiling(True)
+    got2, st2 = batched(p, prms, [2, 3])
+    p.set_profiling(False)
+    for k in acc:
+        assert words_equal(got2[k], acc[k].reshape(got2[k].shape)), ("stages apart", k)
+    for k in ("samples", "rays_extend", "rays_shadow", "rays_shadow_null", "rays_retraced"):
+        assert st[k] == st2[k], k
+    p.destroy()
+    sb.release()
