@@ -74,6 +74,7 @@ def parse():
                     help="pt_pass_set_material_grouping: -1 the library's choice (a lone draw: escaped paths apart from vertex 1 on), 0 no grouping, 1 by material type")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank control flow on ONE GPU: all ranks use device 0, gloo backend, collectives staged through the host")
+    ap.add_argument("--one-scaling", action="store_true", help="with --gpus N > 1: do not time the other scaling mode as well")
     ap.add_argument("--dump", default=None, help="rank 0 writes the final output buffers to this .npz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel events (no roofline)")
@@ -131,9 +132,13 @@ def main():
 
     wl = args.workload
     steps = args.steps if args.steps is not None else (96 if wl == "casa_pt" else (8 if wl == "casa_isect" else 18))
-    if args.batch <= 0:
-        mine = steps if (world == 1 or args.scaling == "weak") else -(-steps // world)
-        args.batch = max(1, min(16, -(-mine // max(args.pipeline, 1))))
+    auto_batch = args.batch <= 0
+
+    def batch_for(n_mine):
+        """Samples per draw for a rank that draws n_mine samples: cut evenly over the draws in flight, 16 at most."""
+        return max(1, min(16, -(-n_mine // max(args.pipeline, 1)))) if auto_batch else args.batch
+    if auto_batch:
+        args.batch = batch_for(steps if (world == 1 or args.scaling == "weak") else -(-steps // world))
     warmup = args.warmup if args.warmup is not None else {"casa_pt": 16, "casa_isect": 2}.get(wl, 4)
 
     t_setup = time.time()
@@ -169,7 +174,7 @@ def main():
     p.set_tail_threshold(args.tail)
     if wl != "casa_isect":
         p.set_pipeline(args.pipeline)
-        p.reserve_batch(args.batch)
+        p.reserve_batch(max(args.batch, batch_for(steps) if world > 1 else 1))
     p.prepare()   # (traversal arrays and the path state of every draw in flight: nothing is allocated inside the timed region)
     ctx.synchronize()
     upload_s = time.perf_counter() - t_up
@@ -212,33 +217,38 @@ def main():
         dominant = ("intersect_fast_kernel + intersect_kernel", prof["intersect_ms"], prof["intersect_launches"], total_rays) if prof else None
     else:
         total_spp = steps * world if args.scaling == "weak" else steps
-        jit = scene.mt19937_jitters(total_spp)
+        jits = {total_spp: scene.mt19937_jitters(total_spp)}   # per frame length: the last sample of a frame sits at the pixel centre
+        jit = jits[total_spp]
         my_samples = multigpu.sample_slice(total_spp, rank, world)  # 1-based global sample indices
 
-        def params_of(global_s, accum_mode):
+        def params_of(global_s, accum_mode, n_spp=None):
             # currentspp carries the GLOBAL sample index (it seeds the sampler); with sums
             # (accum_mode 1) the accumulation weight does not depend on it
-            return scene.make_params(W, H, v2w, sky, spp=global_s, frame=1, jitter=jit[(global_s - 1) % total_spp],
+            n_spp = n_spp or total_spp
+            if n_spp not in jits:
+                jits[n_spp] = scene.mt19937_jitters(n_spp)
+            return scene.make_params(W, H, v2w, sky, spp=global_s, frame=1, jitter=jits[n_spp][(global_s - 1) % n_spp],
                                      max_depth=args.depth, light_count=len(sd.lights), accum_mode=accum_mode)
 
         def draw(global_s, accum_mode):
             p.set_params(params_of(global_s, accum_mode))
             p.draw()
 
-        def prepare_params(samples, accum_mode):
+        def prepare_params(samples, accum_mode, n_spp=None):
             """The parameter sets of the samples, made ahead of the draws (in the reference the host sets twenty uniforms per
             sample, main.cpp:185-205; here each set is a Python object with two matrix products behind it)."""
-            return [params_of(s, accum_mode) for s in samples]
+            return [params_of(s, accum_mode, n_spp) for s in samples]
 
-        def draw_all(prms):
+        def draw_all(prms, batch=None):
             """The samples in order: one pt_pass_draw each, or pt_pass_draw_batch calls of --batch samples."""
-            if args.batch <= 1:
+            batch = batch or args.batch
+            if batch <= 1:
                 for prm in prms:
                     p.set_params(prm)
                     p.draw()
                 return
-            for k in range(0, len(prms), args.batch):
-                p.draw_batch(prms[k:k + args.batch])
+            for k in range(0, len(prms), batch):
+                p.draw_batch(prms[k:k + batch])
 
         draw_all(prepare_params(range(1, 1 + warmup), 0))
         note("warm-up draws queued")
@@ -273,22 +283,40 @@ def main():
             for name in multigpu.ACCUMULATED:   # sums start from zero on every rank
                 p.outputs[name].fill(0.0)
         p.set_pipeline(args.pipeline)
-        timed_params = prepare_params(my_samples, accum_mode)
-        barrier()
-        p.stats(reset=True)
-        t0 = time.perf_counter()
-        draw_all(timed_params)
-        if world > 1:
-            ctx.synchronize()                      # this rank's slice is drawn
-            draw_s = time.perf_counter() - t0
-            combine(total_spp)                     # (waits for the collectives)
-            combine_s = time.perf_counter() - t0 - draw_s   # includes waiting for the slowest rank's slice
-        barrier()
-        dt = time.perf_counter() - t0
+
+        def timed_frame(n_spp, samples, batch=None):
+            """One frame of n_spp samples in all, of which this rank draws `samples`: barrier, draws, combine, barrier."""
+            prms = prepare_params(samples, accum_mode, n_spp)
+            barrier()
+            p.stats(reset=True)
+            t_a = time.perf_counter()
+            draw_all(prms, batch)
+            d_s = c_s = None
+            if world > 1:
+                ctx.synchronize()                      # this rank's slice is drawn
+                d_s = time.perf_counter() - t_a
+                combine(n_spp)                         # (waits for the collectives)
+                c_s = time.perf_counter() - t_a - d_s  # includes waiting for the slowest rank's slice
+            barrier()
+            return time.perf_counter() - t_a, prms, d_s, c_s, p.stats(reset=True)
+
+        dt, timed_params, draw_s, combine_s, st = timed_frame(total_spp, my_samples)
         note("timed region done")
-        st = p.stats(reset=True)
         if args.dump and rank == 0:
             np.savez(args.dump, **p.download())
+        other = None
+        if world > 1 and not args.one_scaling:
+            # the other way of cutting the work, timed the same way (not `value`): a flat strong-scaling curve of a small
+            # frame and a steep weak-scaling one say different things, so the line carries both
+            o_mode = "weak" if args.scaling == "strong" else "strong"
+            o_spp = steps * world if o_mode == "weak" else steps
+            for name in multigpu.ACCUMULATED:
+                p.outputs[name].fill(0.0)
+            o_samples = multigpu.sample_slice(o_spp, rank, world)
+            o_dt, _, o_draw, o_comb, o_st = timed_frame(o_spp, o_samples, batch_for(len(list(o_samples))))
+            other = dict(scaling=o_mode, dt=o_dt, total_spp=o_spp, rays=o_st["rays_extend"] + o_st["rays_shadow"] - o_st["rays_shadow_null"],
+                         samples=o_st["samples"], draw_ms=o_draw * 1e3, combine_ms=o_comb * 1e3)
+            note("the other scaling mode timed")
         # rays = queries that were TRACED: the reference's occlusion queries for light samples that are exactly
         # zero (pt_stats.rays_shadow_null) are decided without a traversal and not counted as work done
         units_per_rank = dict(rays=st["rays_extend"] + st["rays_shadow"] - st["rays_shadow_null"], samples=st["samples"],
@@ -369,6 +397,8 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {"draw_ms": (draw_s or 0.0) * 1e3, "combine_ms": (combine_s or 0.0) * 1e3,
                                           "samples": len(list(my_samples)) if wl != "casa_isect" else None})
+        other_all = [None] * world
+        dist.all_gather_object(other_all, other if wl != "casa_isect" else None)
     else:
         total_rays, total_samples = float(units_per_rank["rays"]), float(units_per_rank["samples"])
 
@@ -404,6 +434,14 @@ def main():
             # scale) as the fastest rank saw it -- the others' figures include waiting for the slowest slice -- and every rank's draw time
             "allreduce_ms": min(r["combine_ms"] for r in per_rank) if world > 1 and wl != "casa_isect" else None,
             "per_rank": per_rank if world > 1 else None,
+            # N > 1: the same job cut the other way (weak: `steps` samples per rank; strong: `steps` samples in all), same timing
+            "other_scaling": ({"scaling": other_all[0]["scaling"], "total_spp": other_all[0]["total_spp"],
+                               "value": sum(o["rays"] for o in other_all) / max(o["dt"] for o in other_all) / 1e6,
+                               "msamples_per_s": sum(o["samples"] for o in other_all) / max(o["dt"] for o in other_all) / 1e6,
+                               "ms_per_step": max(o["dt"] for o in other_all) / steps * 1e3,
+                               "allreduce_ms": min(o["combine_ms"] for o in other_all),
+                               "draw_ms_per_rank": [o["draw_ms"] for o in other_all]}
+                              if world > 1 and other_all[0] else None),
             "retraced_fraction_of_extend_rays": (units_per_rank.get("retraced", 0) / units_per_rank["rays_extend"])
                                                 if units_per_rank.get("rays_extend") else None,
             "rays_per_sample": (total_rays / total_samples) if total_samples else None,

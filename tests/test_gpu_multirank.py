@@ -41,6 +41,9 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
     assert out["allreduce_ms"] > 0 and len(out["per_rank"]) == 2 and all(r["samples"] == 3 and r["draw_ms"] > 0 for r in out["per_rank"])
+    # the same job cut the other way rides along in the line: 3 samples in all over the two ranks
+    o = out["other_scaling"]
+    assert o["scaling"] == "strong" and o["total_spp"] == 3 and o["value"] > 0 and len(o["draw_ms_per_rank"]) == 2
     # strong scaling (the default with more than one rank): the same 6 samples, now as --steps 6 cut over the two ranks
     three = str(tmp_path / "three.npz")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -49,6 +52,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out3 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out3["scaling"] == "strong" and out3["config"]["total_spp"] == 6
+    assert out3["other_scaling"]["scaling"] == "weak" and out3["other_scaling"]["total_spp"] == 12
     c = np.load(three)
     b2 = np.load(two)
     for name in b2.files:
