@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Differential test of whole draws on the GPU against the CPU oracle: random scenes (tools/flat_fuzz.py's geometry
 with random conductor / rough dielectric materials, sometimes textured, 0-3 analytic lights), a camera looking at
-them, random MAX_DEPTH and sampling switches, two accumulated draws; every traversal mode, draws in flight or one at
-a time, tail launch forced / off / the library's choice.  All seven outputs must equal the oracle's word for word.
+them, random MAX_DEPTH and sampling switches, three accumulated samples; every traversal mode, draws in flight or one at
+a time, tail launch forced / off / the library's choice, single draws and batched ones.  All seven outputs must equal the oracle's word for word.
 Usage: python tools/render_fuzz.py [n_scenes] [seed]"""
 import os
 import sys
@@ -72,8 +72,8 @@ def run(n_scenes, seed, ctx, verbose=True):
         pitch = float(np.degrees(np.arcsin(np.clip(to[1], -1, 1))))
         v2w = scene.transform_matrix(tuple(cam_pos), (pitch, yaw, 0.0), (1, 1, 1))
         depth = int(rng.choice([0, 1, 2, 4, 7, 12]))
-        jit = scene.mt19937_jitters(2)
-        prms = [scene.make_params(w, h, v2w, sky, spp=s, frame=1, jitter=jit[s - 1], max_depth=depth, light_count=len(sd.lights)) for s in (1, 2)]
+        jit = scene.mt19937_jitters(3)
+        prms = [scene.make_params(w, h, v2w, sky, spp=s, frame=1, jitter=jit[s - 1], max_depth=depth, light_count=len(sd.lights)) for s in (1, 2, 3)]
         osc = oracle.OracleScene(sd, sky)
         ref = None
         for prm in prms:
@@ -81,21 +81,30 @@ def run(n_scenes, seed, ctx, verbose=True):
         sb = device.SceneBuffers(ctx, sd, sky)
         fails = []
         for traversal in (0, 1, 2, 3):
-            for pipeline, tail in ((3, -1), (1, 1 << 30), (1, 0)):
+            # single draws; the three samples as one draw with the scene laid out ahead (camera rays as tiles, shaded where they
+            # are traced); one sample, then two in one draw (whose halves go through the two kinds of primary launch)
+            for pipeline, tail, how in ((3, -1, "single"), (1, 1 << 30, "single"), (1, 0, "single"), (1, -1, "batch"), (3, -1, "1+2")):
                 p = device.PathTracingPass(ctx, w, h)
                 p.bind_scene(sb)
                 p.set_traversal(traversal)
                 p.set_pipeline(pipeline)
                 p.set_tail_threshold(tail)
-                for prm in prms:
-                    p.set_params(prm)
-                    p.draw()
-                    if pipeline == 1:
-                        ctx.synchronize()
+                if how == "single":
+                    for prm in prms:
+                        p.set_params(prm)
+                        p.draw()
+                        if pipeline == 1:
+                            ctx.synchronize()
+                elif how == "batch":
+                    p.prepare()
+                    p.draw_batch(prms)
+                else:
+                    p.draw_batch(prms[:1])
+                    p.draw_batch(prms[1:])
                 out = p.download()
                 wrong = [key for key in ref if not bit_equal(out[key], ref[key])]
                 if wrong:
-                    fails.append((traversal, pipeline, tail, wrong))
+                    fails.append((traversal, pipeline, tail, how, wrong))
                 p.destroy()
         sb.release()
         covered = float((np.asarray(ref["instanceIndex"]) >= 0).mean())
