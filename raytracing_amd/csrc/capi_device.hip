@@ -142,8 +142,10 @@ struct pt_pass {
     // is faster depends on how many triangles a tile of 8 x 8 pixels sees (few: the tile's rays share their walk; many:
     // every lane pays for the union of 64 walks), so the pass times a launch of each kind (events on the draw's
     // stream, read when they have completed, no wait) and keeps the faster one until the flattened tree is rebuilt: on the
-    // first draw that carries two samples or more, one half of the samples goes through each kind (the same image, so the
-    // two figures compare); draws of one sample are timed one kind per draw and compared when their sizes are equal.
+    // second draw that carries four samples or more, one half of the samples goes through each kind (the same image, so the
+    // two figures compare); draws of fewer samples are timed one kind per draw and compared when their sizes are equal.
+    // The two sorts of draw are decided apart ([0]: up to three samples, [1]: more): a launch over one sample's tiles waits
+    // for its slowest walk, one over eight samples' fills the chip, and the kinds do not rank the same in both.
     // Results do not depend on the choice.
     struct PrimaryTuner {
         hipEvent_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
@@ -154,7 +156,7 @@ struct pt_pass {
         double ms_per_slot[2] = {0.0, 0.0};
         int decided = -1;
         uint64_t flat_build = 0;  // the flattened tree the measurements belong to
-    } primary_tuner;
+    } primary_tuner[2];
     hipEvent_t last_gbuf = nullptr, last_fin = nullptr;  // of the previous draw; null before the first
     hipStream_t cur_stream = nullptr;                    // stream the ScopedTimer records on
     DeviceArray d_counters, d_stats, d_err;  // d_err: traversal counters of RT_TRACE_STATS builds (bytes 16..47)
@@ -1008,8 +1010,9 @@ int pt_pass_destroy(pt_pass *p) {
     if(p->d_accum_group) (void)hipFree(p->d_accum_group);
     if(p->d_lastwrite_group) (void)hipFree(p->d_lastwrite_group);
     collect_profile(p);
-    for(hipEvent_t e : {p->primary_tuner.a[0], p->primary_tuner.a[1], p->primary_tuner.b[0], p->primary_tuner.b[1]})
-        if(e) (void)hipEventDestroy(e);
+    for(pt_pass::PrimaryTuner &tu : p->primary_tuner)
+        for(hipEvent_t e : {tu.a[0], tu.a[1], tu.b[0], tu.b[1]})
+            if(e) (void)hipEventDestroy(e);
     for(hipEvent_t e : p->event_pool) (void)hipEventDestroy(e);
     for(pt_pass::Lane &l : p->lanes) release_lane(l);
     DeviceArray *arrs[] = {&p->d_mesh_buf, &p->d_scene_buf, &p->d_flat_buf, &p->d_redo_isect,
@@ -1179,7 +1182,7 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     int tuner_kind = -1;       // >= 0: this draw's primary launch is timed as a measurement of that kind
     bool tuner_halves = false;  // this draw's samples go half through each kind, both timed
     if(packets_possible && packets_forced < 0) {
-        pt_pass::PrimaryTuner &tu = p->primary_tuner;
+        pt_pass::PrimaryTuner &tu = p->primary_tuner[n >= 4 ? 1 : 0];
         if(tu.flat_build != p->flat_builds) {  // another tree: measure again
             tu.flat_build = p->flat_builds;
             tu.decided = -1;
@@ -1207,14 +1210,14 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
             packets = tu.decided == 1;
         } else if(cold || p->profiling || tu.pending[0] || tu.pending[1]) {
             packets = true;  // (not to be timed, a measurement is under way, or the per-kernel profile is being taken: the likelier kind)
-        } else if(n >= 2) {
+        } else if(n >= 4) {
             for(int k = 0; k < 2; k++)
                 for(hipEvent_t *e : {&tu.a[k], &tu.b[k]})
                     if(!*e) HIP_TRY(hipEventCreate(e));
             tuner_halves = true;
             if(getenv("RTA_TUNER_LOG")) fprintf(stderr, "primary launch: timing both kinds on a draw of %d samples\n", n);
         } else {
-            // one sample per draw: the kind that has no figure yet (packets first)
+            // a thin draw: the kind that has no figure yet (packets first)
             const int k = tu.ms_per_slot[1] == 0.0 ? 1 : 0;
             for(hipEvent_t *e : {&tu.a[k], &tu.b[k]})
                 if(!*e) HIP_TRY(hipEventCreate(e));
@@ -1242,7 +1245,7 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
         if(ordered) {
             if(dep == 0 && fused_primary && tuner_halves) {
                 // the first samples as packets, the others one ray per lane, each launch between two events
-                pt_pass::PrimaryTuner &tu = p->primary_tuner;
+                pt_pass::PrimaryTuner &tu = p->primary_tuner[1];
                 const unsigned first = (unsigned)(n / 2) * (unsigned)npix1, rest = (unsigned)npix - first;
                 (void)hipEventRecord(tu.a[1], s);
                 launch_primary_fast(s, fsc, grid, dp, cnt + CNT_NEXT, qr, cnt + CNT_REDO, true, 0u, first, true);
@@ -1255,13 +1258,14 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
                 tu.pending[0] = tu.pending[1] = true;
                 tu.halves[0] = tu.halves[1] = true;
             } else if(dep == 0 && fused_primary) {
-                if(tuner_kind >= 0) (void)hipEventRecord(p->primary_tuner.a[tuner_kind], s);
+                pt_pass::PrimaryTuner &tu = p->primary_tuner[0];  // (draws of up to three samples are timed whole)
+                if(tuner_kind >= 0) (void)hipEventRecord(tu.a[tuner_kind], s);
                 launch_primary_fast(s, fsc, grid, dp, cnt + CNT_NEXT + 2 * dep, qr, cnt + CNT_REDO + dep, packets, 0u, (unsigned)npix, true);
                 if(tuner_kind >= 0) {
-                    (void)hipEventRecord(p->primary_tuner.b[tuner_kind], s);
-                    p->primary_tuner.slots[tuner_kind] = npix;
-                    p->primary_tuner.pending[tuner_kind] = true;
-                    p->primary_tuner.halves[tuner_kind] = false;
+                    (void)hipEventRecord(tu.b[tuner_kind], s);
+                    tu.slots[tuner_kind] = npix;
+                    tu.pending[tuner_kind] = true;
+                    tu.halves[tuner_kind] = false;
                 }
             }
             else
