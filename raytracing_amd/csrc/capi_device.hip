@@ -1206,9 +1206,14 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
                 fprintf(stderr, "primary launch: %.3f ns per slot one ray per lane (%zu slots), %.3f as tiles (%zu slots): %s\n",
                         tu.ms_per_slot[0] * 1e6, tu.slots[0], tu.ms_per_slot[1] * 1e6, tu.slots[1], tu.decided ? "tiles" : "per lane");
         }
+        // Nothing to time where a tile of 8 x 8 pixels sees a triangle or two: fewer than one (instance, triangle) pair per
+        // four pixels (the demo scene at 1920x1080: one per sixty, tiles 42 % faster; ten million triangles at 3840x2160: 1.2
+        // per pixel, tiles 2.5 % slower -- that side of the line is measured).  A timed draw costs: its vertex 0 runs as three
+        // launches instead of one.
+        const bool sparse = (double)p->flat.n_leaves * 4.0 < (double)npix1;
         if(tu.decided >= 0) {
             packets = tu.decided == 1;
-        } else if(cold || p->profiling || tu.pending[0] || tu.pending[1]) {
+        } else if(sparse || cold || p->profiling || tu.pending[0] || tu.pending[1]) {
             packets = true;  // (not to be timed, a measurement is under way, or the per-kernel profile is being taken: the likelier kind)
         } else if(n >= 4) {
             for(int k = 0; k < 2; k++)
