@@ -303,7 +303,7 @@ void launch_generate(hipStream_t s, const DrawParams &dp) {
 void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,
                   unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group, bool group_materials,
                   bool listed_only) {
-    const dim3 grid(shade_grid(listed_only ? 4096 : dp.npix)), block(SHADE_BLOCK);
+    const dim3 grid(shade_grid(dp.npix)), block(SHADE_BLOCK);  // (blocks beyond the queue's end leave at once)
     if(dep == 0 && dp.p.RasterizaionFor1st != 0)
         hipLaunchKernelGGL((shade_kernel<1, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, listed_only);
     else if(dep == 0 && dp.raster_outputs)
