@@ -464,6 +464,12 @@ int pt_host_mat4_mul(const float a[16], const float b[16], float out16[16]);
 int pt_host_mat4_inverse(const float m[16], float out16[16]);
 /* Camera::projection, src/instance/Camera.cpp:21-43 */
 int pt_host_camera_projection(float fov_x, float far_plane, int32_t screen_w, int32_t screen_h, float out16[16]);
+/* The jitters of one frame as update() draws them, main.cpp:56 and :169-172: std::mt19937 globalRand(0), per sample two
+ * draws divided by max() in float (x first: the order of the two draws inside the vec2 constructor is unspecified in
+ * C++; this is the choice made here), the last sample of a frame at the pixel centre unless Config::useStaticBlender.
+ * frame: how many frames of spp_per_frame samples have been drawn before (the generator runs on from frame to frame).
+ * xy: 2 * spp_per_frame floats. */
+int pt_host_frame_jitters(uint64_t frame, int32_t spp_per_frame, int32_t static_blender, float *xy);
 /* HDRLoader::load, include/hdrloader.cpp:29-116, from memory.  Call with rgb_out NULL
  * to get the size. */
 int pt_host_rgbe_decode(const void *bytes, size_t n, int32_t *w, int32_t *h, float *rgb_out);

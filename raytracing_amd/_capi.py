@@ -148,6 +148,7 @@ SIGNATURES = {
     "pt_host_mat4_mul": (C.c_int, [f32p, f32p, f32p]),
     "pt_host_mat4_inverse": (C.c_int, [f32p, f32p]),
     "pt_host_camera_projection": (C.c_int, [C.c_float, C.c_float, C.c_int32, C.c_int32, f32p]),
+    "pt_host_frame_jitters": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, f32p]),
     "pt_host_rgbe_decode": (C.c_int, [C.c_void_p, C.c_size_t, i32p, i32p, f32p]),
     "pt_host_rgbe_encode": (C.c_int64, [f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
     "pt_host_sky_cache": (C.c_int, [f32p, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_double)]),

@@ -1,5 +1,6 @@
 // Host-only half of the C ABI: scene-buffer producers.  Nothing here calls HIP.
 #include <cstring>
+#include <random>
 #include <thread>
 #include <vector>
 #include "capi_common.h"
@@ -172,6 +173,20 @@ int pt_host_camera_projection(float fov_x, float far_plane, int32_t screen_w, in
     if(!out16 || screen_w <= 0 || screen_h <= 0) return fail(PT_ERR_INVALID, "pt_host_camera_projection: bad argument");
     Mat4 m = camera_projection(fov_x, far_plane, screen_w, screen_h);
     memcpy(out16, m.data(), 64);
+    return PT_OK;
+}
+
+int pt_host_frame_jitters(uint64_t frame, int32_t spp_per_frame, int32_t static_blender, float *xy) {
+    if(!xy || spp_per_frame <= 0) return fail(PT_ERR_INVALID, "pt_host_frame_jitters: bad argument");
+    std::mt19937 rand(0);
+    rand.discard(frame * 2ull * (uint64_t)spp_per_frame);
+    for(int32_t s = 0; s < spp_per_frame; s++) {
+        const float x = (float)rand() * 1.0f / (float)rand.max();
+        const float y = (float)rand() * 1.0f / (float)rand.max();
+        const bool centre = !static_blender && s == spp_per_frame - 1;
+        xy[2 * s] = centre ? 0.5f : x;
+        xy[2 * s + 1] = centre ? 0.5f : y;
+    }
     return PT_OK;
 }
 
