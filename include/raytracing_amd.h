@@ -214,6 +214,9 @@ typedef struct pt_stats {
      * whether they are visible or not (shader/pathtracing.glsl:516-528 and :531-554 trace them first and evaluate
      * afterwards): the sky's at every vertex, those of analytic lights from the second vertex on. */
     uint64_t rays_shadow_null;
+    /* Of rays_extend: the rays of vertex 1 that left their 8 x 8-pixel tile in nearly one direction (a polished floor, a
+     * pane) and were therefore walked through the tree as one group per tile, like the camera rays before them. */
+    uint64_t rays_extend_grouped;
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 

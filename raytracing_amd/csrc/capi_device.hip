@@ -26,6 +26,7 @@ constexpr int CNT_NEXT_REDO = 350;  // [350, 420): next-ray counters of those la
 constexpr int CNT_INTERSECT = 420;  // next-ray, redo count, next-ray of the redo launch
 constexpr int CNT_TAIL = 424;       // batch counter of the tail launch
 constexpr int CNT_TUNE = 425;       // next-ray counter of the second primary launch of a draw that times both kinds
+constexpr int CNT_GROUPS = 426;     // groups in the packet queue of vertex 1, the paths in them (427), next-group counter of their launch (428)
 constexpr int CNT_SHADOW_REDO = 432;       // [432, 502): occlusion queries the ordered traversal left undecided, per vertex
 constexpr int CNT_NEXT_SHADOW_REDO = 502;  // [502, 572): next-ray counters of the launches that trace those
 constexpr int CNT_TOTAL = 572;
@@ -127,7 +128,7 @@ struct pt_pass {
     // the first vertex, and the running mean in finalize.
     struct Lane {
         hipStream_t stream = nullptr;
-        DeviceArray rays, hits, thr, acc, shadow, queue_a, queue_b, queue_s, queue_r, queue_sr, counters, spill;
+        DeviceArray rays, hits, thr, acc, shadow, queue_a, queue_b, queue_s, queue_r, queue_sr, queue_p, counters, spill;
         int shadow_capacity = 0;
         int batch_capacity = 0;  // samples per draw the path state is sized for
         int spill_depth = 0;
@@ -607,7 +608,7 @@ void release_lane(pt_pass::Lane &l) {
             (void)hipEventDestroy(*e);
             *e = nullptr;
         }
-    DeviceArray *arrs[] = {&l.rays, &l.hits, &l.thr, &l.acc, &l.shadow, &l.queue_a, &l.queue_b, &l.queue_s, &l.queue_r, &l.queue_sr, &l.counters, &l.spill};
+    DeviceArray *arrs[] = {&l.rays, &l.hits, &l.thr, &l.acc, &l.shadow, &l.queue_a, &l.queue_b, &l.queue_s, &l.queue_r, &l.queue_sr, &l.queue_p, &l.counters, &l.spill};
     for(DeviceArray *a : arrs) a->release();
     l = pt_pass::Lane();
 }
@@ -637,6 +638,7 @@ int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow, int batch) {
         if(!rc) rc = l.queue_b.ensure(npix * 4);
         if(!rc) rc = l.queue_s.ensure(npix * 4);
         if(!rc) rc = l.queue_r.ensure(2 * npix * 4);  // undecided extend rays and given-up occlusion queries of one vertex
+        if(!rc) rc = l.queue_p.ensure(npix * 4);      // groups of 64 paths that leave a tile in nearly one direction (vertex 1)
         if(!rc) rc = l.counters.ensure(CNT_TOTAL * 4);
         if(!rc) rc = l.shadow.ensure(npix * n_shadow * sizeof(ShadowEntry));
         // (with analytic lights: the occlusion queries of one vertex that the ordered traversal leaves undecided)
@@ -1288,12 +1290,18 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     static const bool fusion_off = getenv("RTA_FUSED_PRIMARY") && atoi(getenv("RTA_FUSED_PRIMARY")) == 0;
     const bool fuse_first = !fusion_off && fused_primary && packets && tuner_kind < 0 && !tuner_halves && !p->profiling && !dp.raster_outputs &&
                             tail_from != 0 && p->material_grouping <= 0;
+    // Tiles whose paths leave in nearly one direction (a polished floor, a pane) are walked as groups once more at vertex 1
+    // (trace_kernels.hip: extend_packet_kernel); RTA_BOUNCE_GROUPS=0: all through the merged launch, a tuning aid.
+    static const bool groups_off = getenv("RTA_BOUNCE_GROUPS") && atoi(getenv("RTA_BOUNCE_GROUPS")) == 0;
+    const bool bounce_groups = fuse_first && !groups_off && merged && tail_from != 1 && P.MAX_DEPTH >= 1;
+    unsigned *qp = bounce_groups ? static_cast<unsigned *>(L.queue_p.p) : nullptr;
     if(fuse_first) {
         // (this launch writes the last-write outputs: after the previous draw's)
         if(p->last_gbuf && p->last_gbuf != L.gbuf) HIP_TRY(hipStreamWaitEvent(s, p->last_gbuf, 0));
-        launch_primary_shade_packets(s, fsc, grid, dp, cnt + CNT_NEXT, qr, cnt + CNT_REDO, qa, cnt + CNT_QUEUE + 1, qs, cnt + CNT_SHADOW);
+        launch_primary_shade_packets(s, fsc, grid, dp, cnt + CNT_NEXT, qr, cnt + CNT_REDO, qa, cnt + CNT_QUEUE + 1, qs, cnt + CNT_SHADOW, qp,
+                                     cnt + CNT_GROUPS, cnt + CNT_GROUPS + 1);
         launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO, dp.rays, dp.hits, cnt + CNT_NEXT_REDO, true);
-        launch_shade(s, dp, 0, qr, cnt + CNT_REDO, qa, cnt + CNT_QUEUE + 1, qs, cnt + CNT_SHADOW, false, false, true);
+        launch_shade(s, dp, 0, qr, cnt + CNT_REDO, qa, cnt + CNT_QUEUE + 1, qs, cnt + CNT_SHADOW, false, false, SHADE_LISTED);
         HIP_TRY(hipEventRecord(L.gbuf, s));
         p->last_gbuf = L.gbuf;
     } else if(!raster_first) {
@@ -1324,6 +1332,9 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
             const bool by_material = p->material_grouping > 0;
             const bool group = by_material || (p->material_grouping < 0 && dep >= 1 && alone);
             launch_shade(s, dp, dep, q_in, cnt + CNT_QUEUE + dep, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, group, by_material);
+            if(dep == 1 && bounce_groups)  // (the paths that reached this vertex as groups)
+                launch_shade(s, dp, dep, qp, cnt + CNT_GROUPS, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, false, false,
+                             SHADE_GROUPS, cnt + CNT_GROUPS + 1);
         }
         if(dep == 0 && !fuse_first) {
             HIP_TRY(hipEventRecord(L.gbuf, s));
@@ -1335,6 +1346,8 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
                 launch_path_trace_fast(s, fsc, grid, q_out, cnt + CNT_QUEUE + dep + 1, qs, cnt + CNT_SHADOW + dep, dp.rays,
                                        dp.hits, dp.shadow, (int)npix, cnt + CNT_NEXT + 2 * dep + 1, qr, cnt + CNT_REDO + dep + 1, dp.thr,
                                        dp.acc, dp.stats + 2);
+                if(dep == 0 && bounce_groups)
+                    launch_extend_packets(s, fsc, grid, qp, cnt + CNT_GROUPS, dp.rays, dp.hits, cnt + CNT_GROUPS + 2, qr, cnt + CNT_REDO + 1);
                 launch_path_redo(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep + 1, dp.rays, dp.hits, dp.shadow, dp.thr, dp.acc,
                                  cnt + CNT_NEXT_REDO + dep + 1);
             } else {
@@ -1484,6 +1497,7 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     out->draws = raw[3];
     out->rays_retraced = raw[4];
     out->rays_shadow_null = raw[5];
+    out->rays_extend_grouped = raw[6];
     out->mesh_level_builds = pass->mesh_level_builds;
     out->flat_leaves = pass->flat_valid ? (uint64_t)pass->flat.n_leaves : 0;
     out->reference_order_forced = pass->mesh_level_valid && pass->scene_level_valid && !(pass->mesh_level.nested && pass->scene_level.nested) ? 1 : 0;

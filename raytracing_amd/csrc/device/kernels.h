@@ -62,7 +62,8 @@ struct DrawParams {
     ShadowEntry *shadow;  // [n_shadow][npix]
     // outputs
     float *o_direct, *o_indirect, *o_albedo, *o_motion, *o_depth, *o_normal, *o_inst;
-    // counters: [0] samples, [1] extend rays, [2] shadow rays, [3] draws, [4] extend rays re-traced in reference order
+    // counters: [0] samples, [1] extend rays, [2] shadow rays, [3] draws, [4] extend rays re-traced in reference order,
+    // [5] light samples that needed no occlusion query, [6] extend rays of vertex 1 walked as groups
     unsigned long long *stats;
     int redo_counter_base;  // index in `counters` of the per-vertex re-trace counts, -1 when there are none
     // per-draw queue counters, zeroed before generate: [d] = paths alive at vertex d
@@ -139,21 +140,33 @@ int packet_stack_entries();
 // the packet form of launch_primary_fast and launch_shade for vertex 0 in one kernel (plain traced first hits only: no
 // raster images in play): a wave shades the pixels of a tile where its walk ends.  Slots it cannot decide are stored and
 // listed in redo as launch_primary_fast does; they want launch_extend(second_pass) and then launch_shade over that list
-// with `listed_only` set.
+// with SHADE_LISTED.
+// packet_queue (may be null): tiles whose paths go on in nearly one direction are listed there as groups of 64 entries
+// (0xFFFFFFFF: no path) instead of in queue_out; *packet_count counts the groups, *packet_valid their paths.  Such groups
+// want launch_extend_packets, and launch_shade with SHADE_GROUPS for the vertex they reach.
 void launch_primary_shade_packets(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter,
                                   unsigned *redo, unsigned *redo_count, unsigned *queue_out, unsigned *count_out,
-                                  unsigned *shadow_queue, unsigned *shadow_count);
+                                  unsigned *shadow_queue, unsigned *shadow_count, unsigned *packet_queue, unsigned *packet_count,
+                                  unsigned *packet_valid);
+// extend rays of those groups, one wave per group (hits and the list of undecided slots as launch_extend_fast)
+void launch_extend_packets(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *group_count,
+                           const PathRay *rays, PathHit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count);
 // shade stage for path vertex `dep` (0 = primary hit).  Appends continuing paths to
 // queue_out and paths with pending light samples to shadow_queue.
 // group: every block first sorts its 256 paths into two groups, so that at most one of its four waves runs the code
 // of both: paths that escaped (a sky lookup, shader/pathtracing.glsl:569-577) behind those that hit something, or,
 // with group_materials, dielectrics behind conductors (the reference dispatches per fragment,
 // shader/materials/materials.glsl:82-111).
-// listed_only: the launch shades the few slots of vertex 0 that launch_primary_shade_packets left to the reference-order
-// pass (queue_in is that list); the rays of the vertex have been counted by that launch.
+// what: SHADE_ALL, the paths of the vertex (queue_in, *count_in);
+//   SHADE_LISTED, the few slots of vertex 0 that launch_primary_shade_packets left to the reference-order pass (queue_in is
+//   that list; the rays of the vertex have been counted by that launch);
+//   SHADE_GROUPS, the paths of the groups in a packet queue (queue_in holds *count_in groups of 64 entries, *valid_count
+//   paths in all), behind the SHADE_ALL launch of the same vertex: their rays are counted, the re-traced ones are not
+//   counted a second time, and the vertex's count of live paths (dp.counters[dep]) is made whole.
+enum ShadeWhat { SHADE_ALL = 0, SHADE_LISTED = 1, SHADE_GROUPS = 2 };
 void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,
                   unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group, bool group_materials,
-                  bool listed_only = false);
+                  ShadeWhat what = SHADE_ALL, const unsigned *valid_count = nullptr);
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,
                          const unsigned *shadow_count);
 void launch_finalize(hipStream_t s, const DrawParams &dp);

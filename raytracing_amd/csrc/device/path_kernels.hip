@@ -72,11 +72,13 @@ template <int RASTER, bool GROUP, bool FIRST>
 __global__ __launch_bounds__(GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(SHADE_WAVES, SHADE_WAVES))) void shade_kernel(DrawParams dp, int dep, const unsigned *queue_in,
                                                             const unsigned *count_in, unsigned *queue_out,
                                                             unsigned *count_out, unsigned *shadow_queue,
-                                                            unsigned *shadow_count, bool group_materials, bool listed_only) {
+                                                            unsigned *shadow_count, bool group_materials, int what,
+                                                            const unsigned *valid_count) {
     constexpr int BLOCK = GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK;
     __shared__ __align__(16) unsigned s_V[SOBOL_NIBBLE_WORDS];
     __shared__ unsigned s_null;  // light samples of this block that needed no occlusion query
-    const unsigned n = *count_in;
+    // (SHADE_GROUPS: the queue holds groups of 64 entries, some of them 0xFFFFFFFF = no path)
+    const unsigned n = what == SHADE_GROUPS ? *count_in * 64u : *count_in;
     const unsigned nthreads = gridDim.x * blockDim.x;
     {
         // (late bounces fill few blocks; block 0 books the counters)
@@ -90,8 +92,14 @@ __global__ __launch_bounds__(GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK) __attribut
 
     if(blockIdx.x == 0 && threadIdx.x == 0) {
         // (with RasterizaionFor1st the first vertex comes from images: no rays were traced for it)
-        if(RASTER != 1 && !listed_only) atomicAdd(&dp.stats[1], FIRST ? (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch : (unsigned long long)n);
-        if(dp.redo_counter_base >= 0) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
+        if(RASTER != 1 && what != SHADE_LISTED)
+            atomicAdd(&dp.stats[1], FIRST ? (unsigned long long)dp.W * (unsigned long long)dp.H * (unsigned long long)dp.batch
+                                          : (unsigned long long)(what == SHADE_GROUPS ? *valid_count : n));
+        if(dp.redo_counter_base >= 0 && what != SHADE_GROUPS) atomicAdd(&dp.stats[4], (unsigned long long)dp.counters[dp.redo_counter_base + dep]);
+        if(what == SHADE_GROUPS) {
+            atomicAdd(&dp.counters[dep], *valid_count);  // (read from here on only as the vertex's count of live paths)
+            atomicAdd(&dp.stats[6], (unsigned long long)*valid_count);
+        }
     }
 
     __shared__ unsigned s_slot[GROUP ? BLOCK : 1];
@@ -115,6 +123,10 @@ __global__ __launch_bounds__(GROUP ? SHADE_GROUP_BLOCK : SHADE_BLOCK) __attribut
             const unsigned q = q0 + threadIdx.x;
             unsigned i = q < n ? (queue_in ? queue_in[q] : q) : 0u;
             bool mine = q < n;
+            if(i == 0xFFFFFFFFu) {  // (an empty place of a group)
+                mine = false;
+                i = 0u;
+            }
             if(GROUP) {
                 // One group goes to the back of the block's paths, the other stays in front, order kept
                 // within each group; which lane shades a path changes nothing about what is computed for it.
@@ -302,23 +314,23 @@ void launch_generate(hipStream_t s, const DrawParams &dp) {
 
 void launch_shade(hipStream_t s, const DrawParams &dp, int dep, const unsigned *queue_in, const unsigned *count_in,
                   unsigned *queue_out, unsigned *count_out, unsigned *shadow_queue, unsigned *shadow_count, bool group, bool group_materials,
-                  bool listed_only) {
+                  ShadeWhat what, const unsigned *valid_count) {
     const dim3 grid(shade_grid(dp.npix)), block(SHADE_BLOCK);  // (blocks beyond the queue's end leave at once)
     if(dep == 0 && dp.p.RasterizaionFor1st != 0)
-        hipLaunchKernelGGL((shade_kernel<1, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, listed_only);
+        hipLaunchKernelGGL((shade_kernel<1, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, (int)what, valid_count);
     else if(dep == 0 && dp.raster_outputs)
-        hipLaunchKernelGGL((shade_kernel<2, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, listed_only);
+        hipLaunchKernelGGL((shade_kernel<2, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, (int)what, valid_count);
     else if(group) {
         int b = (dp.npix + SHADE_GROUP_BLOCK - 1) / SHADE_GROUP_BLOCK;
         b = b < 1 ? 1 : (b > 4096 ? 4096 : b);
         if(dep == 0)
-            hipLaunchKernelGGL((shade_kernel<0, true, true>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials, listed_only);
+            hipLaunchKernelGGL((shade_kernel<0, true, true>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials, (int)what, valid_count);
         else
-            hipLaunchKernelGGL((shade_kernel<0, true, false>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials, listed_only);
+            hipLaunchKernelGGL((shade_kernel<0, true, false>), dim3(b), dim3(SHADE_GROUP_BLOCK), 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, group_materials, (int)what, valid_count);
     } else if(dep == 0)
-        hipLaunchKernelGGL((shade_kernel<0, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, listed_only);
+        hipLaunchKernelGGL((shade_kernel<0, false, true>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, (int)what, valid_count);
     else
-        hipLaunchKernelGGL((shade_kernel<0, false, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, listed_only);
+        hipLaunchKernelGGL((shade_kernel<0, false, false>), grid, block, 0, s, dp, dep, queue_in, count_in, queue_out, count_out, shadow_queue, shadow_count, false, (int)what, valid_count);
 }
 
 void launch_shadow_apply(hipStream_t s, const DrawParams &dp, const unsigned *shadow_queue,

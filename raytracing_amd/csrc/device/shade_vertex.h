@@ -77,9 +77,11 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 // (throughput update, escape to the sky) and the launches of later vertices none of the first-hit outputs.
 // given: the closest hit of the slot's ray when the caller holds it in registers (the launch that traces the camera rays
 // and shades their hits in one go); null: it is read from dp.hits[i].
+// next_dir: when not null and the path continues, the direction of its next ray (what was stored in dp.rays[i]).
 template <int RASTER, bool FIRST>
 __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsigned i, const unsigned *s_T, bool &continues,
-                                             bool &has_shadow, unsigned &null_shadow, const LaneHit *given = nullptr) {
+                                             bool &has_shadow, unsigned &null_shadow, const LaneHit *given = nullptr,
+                                             V3 *next_dir = nullptr) {
     continues = false;
     has_shadow = false;
     null_shadow = 0u;
@@ -348,6 +350,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
     float4 *rw = reinterpret_cast<float4 *>(dp.rays + i);
     rw[0] = make_float4(position.x, position.y, position.z, fabsf(bRec.wo.z));
     rw[1] = make_float4(gwo.x, gwo.y, gwo.z, 0.0f);
+    if(next_dir) *next_dir = gwo;
     tp[0] = make_float4(history.x, history.y, history.z, pdf);
     tp[1] = make_float4(fr.x, fr.y, fr.z, __uint_as_float(cx.rng.dim));
 

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_packet_kernel(
         dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
     }
     PrimarySinkFast sink{dp, redo, redo_count, base};
-    trace_flat_packets(sc, dp, sink, next_counter, count, base);
+    trace_flat_packets(sc, CameraRays{dp, base}, sink, next_counter, count);
 }
 
 // The packet launch and the shade launch of vertex 0 as ONE kernel.  The walk of a tile is bound by vector-ALU issue,
@@ -238,24 +238,61 @@ __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void primary_packet_kernel(
 #endif
 constexpr int PRIMARY_SHADE_ROUND = RT_PRIMARY_SHADE_ROUND;
 
+// Where the rays that LEAVE a tile are as alike as the camera rays that reached it -- a tile on a polished floor or a
+// pane: the demo scene's loader turns roughnessFactor 0 into the 0.001 lobe, whose samples stay within a tenth of a
+// degree of the mirror direction -- they are worth walking as a group again.  The wave that shaded the tile knows: when
+// at least PACKET_MIN_LANES of its paths go on and their new directions lie within PACKET_SPREAD of each other in every
+// component, the tile's paths are listed as a group of 64 entries (PACKET_NONE for the lanes that do not go on) in a
+// queue of their own instead of the queue of vertex 1; extend_packet_kernel walks such groups, the merged launch the rest.
+#ifndef RT_PACKET_SPREAD
+#define RT_PACKET_SPREAD 0.06f
+#endif
+#ifndef RT_PACKET_MIN_LANES
+#define RT_PACKET_MIN_LANES 32
+#endif
+constexpr unsigned PACKET_NONE = 0xFFFFFFFFu;
+
+// floats as unsigned integers in the same order (NaNs beyond the infinities)
+__device__ __forceinline__ unsigned float_order(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_of_order(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
 struct PrimaryShadeSink {
     const DrawParams &dp;
     unsigned *redo, *redo_count;
     const unsigned *s_T;   // the Sobol table in LDS
     unsigned *stage;       // this wave's PRIMARY_SHADE_ROUND x 64 words of LDS
     unsigned *queue_out, *count_out, *shadow_queue, *shadow_count;
+    unsigned *packet_queue, *packet_count, *packet_valid;  // groups of coherent bounce rays (null: none are made)
     unsigned staged, cont_bits, shad_bits, null_count;
+    unsigned group_tiles;  // bit u: staged tile u goes to the packet queue (the same in every lane)
+    unsigned group_bits;   // bit u: this lane's path of staged tile u is one of that group
 
     __device__ void tile(unsigned i, bool pixel, const LaneHit &h, bool ambiguous) {
         const unsigned lane = threadIdx.x & 63u;
         bool continues = false, has_shadow = false;
+        V3 nd = v3(0.0f);
         if(pixel) {
             if(ambiguous) {
                 PrimarySinkFast{dp, redo, redo_count, 0u}.store(i, h, true);
             } else {
                 unsigned null_shadow;
-                shade_vertex<0, true>(dp, 0, i, s_T, continues, has_shadow, null_shadow, &h);
+                shade_vertex<0, true>(dp, 0, i, s_T, continues, has_shadow, null_shadow, &h, &nd);
                 null_count += null_shadow;
+            }
+        }
+        if(packet_queue && __popcll(__ballot(continues)) >= RT_PACKET_MIN_LANES) {
+            const float dx = float_of_order(wave_umax(continues ? float_order(nd.x) : 0u)) - float_of_order(wave_umin(continues ? float_order(nd.x) : 0xFFFFFFFFu));
+            const float dy = float_of_order(wave_umax(continues ? float_order(nd.y) : 0u)) - float_of_order(wave_umin(continues ? float_order(nd.y) : 0xFFFFFFFFu));
+            const float dz = float_of_order(wave_umax(continues ? float_order(nd.z) : 0u)) - float_of_order(wave_umin(continues ? float_order(nd.z) : 0xFFFFFFFFu));
+            if(fmaxf(dx, fmaxf(dy, dz)) < RT_PACKET_SPREAD) {  // (a NaN anywhere: no)
+                group_tiles |= 1u << staged;
+                group_bits |= (continues ? 1u : 0u) << staged;
+                continues = false;  // not in the queue of vertex 1
             }
         }
         stage[staged * 64u + lane] = i;
@@ -265,6 +302,25 @@ struct PrimaryShadeSink {
     }
     __device__ void flush() {
         const unsigned lane = threadIdx.x & 63u;
+        if(group_tiles) {
+            const unsigned n_groups = (unsigned)__popc(group_tiles);
+            unsigned valid = 0u;
+#pragma unroll 1
+            for(unsigned u = 0; u < staged; u++) valid += (unsigned)__popcll(__ballot((group_bits >> u) & 1u));
+            unsigned g = 0u;
+            if(lane == 0u) {
+                g = atomicAdd(packet_count, n_groups);
+                atomicAdd(packet_valid, valid);
+            }
+            g = __builtin_amdgcn_readfirstlane(g);
+#pragma unroll 1
+            for(unsigned u = 0; u < staged; u++)
+                if((group_tiles >> u) & 1u) {
+                    packet_queue[(size_t)g * 64u + lane] = ((group_bits >> u) & 1u) ? stage[u * 64u + lane] : PACKET_NONE;
+                    ++g;
+                }
+            group_tiles = group_bits = 0u;
+        }
         unsigned tot_c = 0u, tot_s = 0u;
 #pragma unroll 1
         for(unsigned u = 0; u < staged; u++) {
@@ -298,7 +354,7 @@ struct PrimaryShadeSink {
 
 __global__ __launch_bounds__(FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void primary_shade_packet_kernel(
     FastScene sc, DrawParams dp, unsigned *next_counter, unsigned *redo, unsigned *redo_count, unsigned *queue_out, unsigned *count_out,
-    unsigned *shadow_queue, unsigned *shadow_count) {
+    unsigned *shadow_queue, unsigned *shadow_count, unsigned *packet_queue, unsigned *packet_count, unsigned *packet_valid) {
     __shared__ __align__(16) unsigned s_V[SOBOL_NIBBLE_WORDS];
     __shared__ unsigned s_stage[PRIMARY_SHADE_ROUND * FAST_BLOCK];
     __shared__ unsigned s_null;
@@ -313,11 +369,43 @@ __global__ __launch_bounds__(FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
         dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
     }
     PrimaryShadeSink sink{dp, redo, redo_count, s_V, s_stage + (threadIdx.x >> 6) * (PRIMARY_SHADE_ROUND * 64), queue_out, count_out,
-                          shadow_queue, shadow_count, 0u, 0u, 0u, 0u};
-    trace_flat_packets(sc, dp, sink, next_counter, (unsigned)dp.npix, 0u);
+                          shadow_queue, shadow_count, packet_queue, packet_count, packet_valid, 0u, 0u, 0u, 0u, 0u, 0u};
+    trace_flat_packets(sc, CameraRays{dp, 0u}, sink, next_counter, (unsigned)dp.npix);
     if(sink.null_count) atomicAdd(&s_null, sink.null_count);
     __syncthreads();
     if(threadIdx.x == 0 && s_null) atomicAdd(&dp.stats[5], (unsigned long long)s_null);
+}
+
+// The extend rays of the groups the launch above listed: one wave per group on one node sequence.
+struct QueuedRays {
+    const unsigned *queue;
+    const PathRay *rays;
+    __device__ bool make(unsigned item, unsigned &slot, V3 &o, V3 &d) const {
+        const unsigned e = queue[item];
+        if(e == PACKET_NONE) return false;
+        slot = e;
+        float oo[3], dd[3];
+        load_path_ray(rays, e, oo, dd);
+        o = v3(oo[0], oo[1], oo[2]);
+        d = v3(dd[0], dd[1], dd[2]);
+        return true;
+    }
+};
+struct GroupExtendSink {
+    PathHit *hits;
+    unsigned *redo, *redo_count;
+    __device__ void tile(unsigned slot, bool has_ray, const LaneHit &h, bool ambiguous) const {
+        if(!has_ray) return;
+        write_path_hit(hits, slot, h);  // (provisional for an ambiguous ray: bounds its second pass)
+        if(ambiguous) redo[atomicAdd(redo_count, 1u)] = slot;
+    }
+    __device__ void finish() const {}
+};
+__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void extend_packet_kernel(FastScene sc, const unsigned *queue, const unsigned *group_count,
+                                                                   const PathRay *rays, PathHit *hits, unsigned *next_counter,
+                                                                   unsigned *redo, unsigned *redo_count) {
+    GroupExtendSink sink{hits, redo, redo_count};
+    trace_flat_packets(sc, QueuedRays{queue, rays}, sink, next_counter, *group_count * 64u);
 }
 
 // ---- shadow ------------------------------------------------------------------------------
@@ -533,9 +621,15 @@ void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const D
 }
 void launch_primary_shade_packets(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter,
                                   unsigned *redo, unsigned *redo_count, unsigned *queue_out, unsigned *count_out,
-                                  unsigned *shadow_queue, unsigned *shadow_count) {
+                                  unsigned *shadow_queue, unsigned *shadow_count, unsigned *packet_queue, unsigned *packet_count,
+                                  unsigned *packet_valid) {
     hipLaunchKernelGGL(primary_shade_packet_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp, next_counter, redo, redo_count,
-                       queue_out, count_out, shadow_queue, shadow_count);
+                       queue_out, count_out, shadow_queue, shadow_count, packet_queue, packet_count, packet_valid);
+}
+void launch_extend_packets(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *group_count,
+                           const PathRay *rays, PathHit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count) {
+    hipLaunchKernelGGL(extend_packet_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, group_count, rays, hits, next_counter, redo,
+                       redo_count);
 }
 
 int packet_stack_entries() { return PACKET_STACK; }

@@ -1,4 +1,5 @@
-// Camera rays through the flattened tree, one WAVE per 8x8-pixel tile walking ONE node sequence.
+// Coherent rays through the flattened tree -- the camera rays of an 8x8-pixel tile, or what leaves such a tile in nearly
+// one direction -- one WAVE per group of 64 walking ONE node sequence.
 //
 // trace_flat.h gives every lane a ray of its own: lanes hold different nodes, some a wide node, some a leaf, some
 // nothing until the wave refills, and a vector instruction of that kernel does work in 26 to 37 of its 64 lanes.  The
@@ -37,25 +38,37 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v) {
 }
 __device__ __forceinline__ unsigned wave_umax(unsigned v) { return ~wave_umin(~v); }
 
+// Rays: bool make(unsigned item, unsigned &slot, V3 &o, V3 &d) -- the ray of work item `item` (a lane of a group of 64)
+// and the path slot it belongs to; false: the item names no ray.
 // Sink: void tile(unsigned slot, bool pixel, const LaneHit &h, bool ambiguous), called by ALL lanes of the wave at the end
-// of a tile's walk (pixel: the lane's slot names a pixel; the other arguments mean something only then), and
-// void finish(), called by all lanes when the wave has no tile left.
-// The launch covers the slots [slot_base, slot_base + n_slots) of the draw, both multiples of 64.
-template <class Sink>
-__device__ __forceinline__ void trace_flat_packets(const FastScene &sc, const DrawParams &dp, Sink &sink, unsigned *next_tile,
-                                                   unsigned n_slots, unsigned slot_base) {
-    WaveRayFeed feed(n_slots);  // hands out whole tiles: batch sizes and n_slots are multiples of 64
+// of a group's walk (pixel: the lane has a ray; the other arguments mean something only then), and
+// void finish(), called by all lanes when the wave has no group left.
+// n_items: a multiple of 64.
+struct CameraRays {  // the camera rays of the slots [base, base + n_items), shader/pathtracing.glsl:604-608
+    const DrawParams &dp;
+    unsigned base;
+    __device__ bool make(unsigned item, unsigned &slot, V3 &o, V3 &d) const {
+        slot = base + item;
+        unsigned px, py, k;
+        if(!state_pixel(dp, slot, px, py, k)) return false;
+        camera_ray(dp.p, dp.samples[k].jitter[0], dp.samples[k].jitter[1], dp.tan_half_fov, px, py, o, d);
+        return true;
+    }
+};
+
+template <class Rays, class Sink>
+__device__ __forceinline__ void trace_flat_packets(const FastScene &sc, const Rays &rays, Sink &sink, unsigned *next_tile,
+                                                   unsigned n_items) {
+    WaveRayFeed feed(n_items);  // hands out whole groups: batch sizes and n_items are multiples of 64
     const unsigned lane = threadIdx.x & 63u;
     for(;;) {
-        unsigned slot = 0;
-        const bool got = feed.take(true, next_tile, n_slots, slot);
+        unsigned item = 0;
+        const bool got = feed.take(true, next_tile, n_items, item);
         if(!__any(got)) break;
-        slot += slot_base;
-        // ---- this lane's camera ray (shader/pathtracing.glsl:604-608) and what trace_flat.h derives from a ray
-        unsigned px = 0, py = 0, k = 0;
-        const bool pixel = got && state_pixel(dp, slot, px, py, k);
+        // ---- this lane's ray and what trace_flat.h derives from a ray
+        unsigned slot = 0;
         V3 ro = v3(0.0f), rd = v3(0.0f, 0.0f, 1.0f);
-        if(pixel) camera_ray(dp.p, dp.samples[k].jitter[0], dp.samples[k].jitter[1], dp.tan_half_fov, px, py, ro, rd);
+        const bool pixel = got && rays.make(item, slot, ro, rd);
         const float wox = ro.x, woy = ro.y, woz = ro.z, wdx = rd.x, wdy = rd.y, wdz = rd.z;
         const float o1 = fabsf(wox) + fabsf(woy) + fabsf(woz);
         const float dm = fmaxf(fabsf(wdx), fmaxf(fabsf(wdy), fabsf(wdz)));
