@@ -217,6 +217,9 @@ typedef struct pt_stats {
     /* Of rays_extend: the rays of vertex 1 that left their 8 x 8-pixel tile in nearly one direction (a polished floor, a
      * pane) and were therefore walked through the tree as one group per tile, like the camera rays before them. */
     uint64_t rays_extend_grouped;
+    /* Of rays_shadow: the sky's light samples of vertex 0 that pointed one way from a tile (an importance-sampled sky sends
+     * most samples to its brightest texels) and were walked as one group per tile too. */
+    uint64_t rays_shadow_grouped;
 } pt_stats;
 int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset);
 

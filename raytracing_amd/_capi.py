@@ -49,7 +49,7 @@ class PtStats(C.Structure):
         ("samples", C.c_uint64), ("rays_extend", C.c_uint64), ("rays_shadow", C.c_uint64),
         ("draws", C.c_uint64), ("rays_retraced", C.c_uint64), ("mesh_level_builds", C.c_uint64),
                 ("scene_level_builds", C.c_uint64), ("debug", C.c_uint64 * 3), ("reference_order_forced", C.c_uint64), ("flat_leaves", C.c_uint64),
-                ("rays_shadow_null", C.c_uint64), ("rays_extend_grouped", C.c_uint64),
+                ("rays_shadow_null", C.c_uint64), ("rays_extend_grouped", C.c_uint64), ("rays_shadow_grouped", C.c_uint64),
     ]
 
 

@@ -27,6 +27,7 @@ constexpr int CNT_INTERSECT = 420;  // next-ray, redo count, next-ray of the red
 constexpr int CNT_TAIL = 424;       // batch counter of the tail launch
 constexpr int CNT_TUNE = 425;       // next-ray counter of the second primary launch of a draw that times both kinds
 constexpr int CNT_GROUPS = 426;     // groups in the packet queue of vertex 1, the paths in them (427), next-group counter of their launch (428)
+constexpr int CNT_SGROUPS = 429;    // the same three for the groups of occlusion queries of vertex 0
 constexpr int CNT_SHADOW_REDO = 432;       // [432, 502): occlusion queries the ordered traversal left undecided, per vertex
 constexpr int CNT_NEXT_SHADOW_REDO = 502;  // [502, 572): next-ray counters of the launches that trace those
 constexpr int CNT_TOTAL = 572;
@@ -128,7 +129,7 @@ struct pt_pass {
     // the first vertex, and the running mean in finalize.
     struct Lane {
         hipStream_t stream = nullptr;
-        DeviceArray rays, hits, thr, acc, shadow, queue_a, queue_b, queue_s, queue_r, queue_sr, queue_p, counters, spill;
+        DeviceArray rays, hits, thr, acc, shadow, queue_a, queue_b, queue_s, queue_r, queue_sr, queue_p, queue_ps, counters, spill;
         int shadow_capacity = 0;
         int batch_capacity = 0;  // samples per draw the path state is sized for
         int spill_depth = 0;
@@ -608,7 +609,7 @@ void release_lane(pt_pass::Lane &l) {
             (void)hipEventDestroy(*e);
             *e = nullptr;
         }
-    DeviceArray *arrs[] = {&l.rays, &l.hits, &l.thr, &l.acc, &l.shadow, &l.queue_a, &l.queue_b, &l.queue_s, &l.queue_r, &l.queue_sr, &l.queue_p, &l.counters, &l.spill};
+    DeviceArray *arrs[] = {&l.rays, &l.hits, &l.thr, &l.acc, &l.shadow, &l.queue_a, &l.queue_b, &l.queue_s, &l.queue_r, &l.queue_sr, &l.queue_p, &l.queue_ps, &l.counters, &l.spill};
     for(DeviceArray *a : arrs) a->release();
     l = pt_pass::Lane();
 }
@@ -639,6 +640,7 @@ int prepare_lane(pt_pass *p, pt_pass::Lane &l, int n_shadow, int batch) {
         if(!rc) rc = l.queue_s.ensure(npix * 4);
         if(!rc) rc = l.queue_r.ensure(2 * npix * 4);  // undecided extend rays and given-up occlusion queries of one vertex
         if(!rc) rc = l.queue_p.ensure(npix * 4);      // groups of 64 paths that leave a tile in nearly one direction (vertex 1)
+        if(!rc) rc = l.queue_ps.ensure(npix * 4);     // groups of a tile's light samples that point one way (vertex 0)
         if(!rc) rc = l.counters.ensure(CNT_TOTAL * 4);
         if(!rc) rc = l.shadow.ensure(npix * n_shadow * sizeof(ShadowEntry));
         // (with analytic lights: the occlusion queries of one vertex that the ordered traversal leaves undecided)
@@ -1295,11 +1297,13 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     static const bool groups_off = getenv("RTA_BOUNCE_GROUPS") && atoi(getenv("RTA_BOUNCE_GROUPS")) == 0;
     const bool bounce_groups = fuse_first && !groups_off && merged && tail_from != 1 && P.MAX_DEPTH >= 1;
     unsigned *qp = bounce_groups ? static_cast<unsigned *>(L.queue_p.p) : nullptr;
+    static const bool sgroups_off = getenv("RTA_SHADOW_GROUPS") && atoi(getenv("RTA_SHADOW_GROUPS")) == 0;
+    unsigned *qps = bounce_groups && !sgroups_off ? static_cast<unsigned *>(L.queue_ps.p) : nullptr;
     if(fuse_first) {
         // (this launch writes the last-write outputs: after the previous draw's)
         if(p->last_gbuf && p->last_gbuf != L.gbuf) HIP_TRY(hipStreamWaitEvent(s, p->last_gbuf, 0));
         launch_primary_shade_packets(s, fsc, grid, dp, cnt + CNT_NEXT, qr, cnt + CNT_REDO, qa, cnt + CNT_QUEUE + 1, qs, cnt + CNT_SHADOW, qp,
-                                     cnt + CNT_GROUPS, cnt + CNT_GROUPS + 1);
+                                     cnt + CNT_GROUPS, cnt + CNT_GROUPS + 1, qps, cnt + CNT_SGROUPS, cnt + CNT_SGROUPS + 1);
         launch_extend(s, sc, p->redo_blocks, qr, cnt + CNT_REDO, dp.rays, dp.hits, cnt + CNT_NEXT_REDO, true);
         launch_shade(s, dp, 0, qr, cnt + CNT_REDO, qa, cnt + CNT_QUEUE + 1, qs, cnt + CNT_SHADOW, false, false, SHADE_LISTED);
         HIP_TRY(hipEventRecord(L.gbuf, s));
@@ -1348,6 +1352,9 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
                                        dp.acc, dp.stats + 2);
                 if(dep == 0 && bounce_groups)
                     launch_extend_packets(s, fsc, grid, qp, cnt + CNT_GROUPS, dp.rays, dp.hits, cnt + CNT_GROUPS + 2, qr, cnt + CNT_REDO + 1);
+                if(dep == 0 && qps)
+                    launch_shadow_packets(s, fsc, grid, qps, cnt + CNT_SGROUPS, cnt + CNT_SGROUPS + 1, dp.rays, dp.shadow, dp.thr, dp.acc,
+                                          cnt + CNT_SGROUPS + 2, qr, cnt + CNT_REDO + 1, dp.stats);
                 launch_path_redo(s, sc, p->redo_blocks, qr, cnt + CNT_REDO + dep + 1, dp.rays, dp.hits, dp.shadow, dp.thr, dp.acc,
                                  cnt + CNT_NEXT_REDO + dep + 1);
             } else {
@@ -1498,6 +1505,7 @@ int pt_pass_stats(pt_pass *pass, pt_stats *out, int reset) {
     out->rays_retraced = raw[4];
     out->rays_shadow_null = raw[5];
     out->rays_extend_grouped = raw[6];
+    out->rays_shadow_grouped = raw[7];
     out->mesh_level_builds = pass->mesh_level_builds;
     out->flat_leaves = pass->flat_valid ? (uint64_t)pass->flat.n_leaves : 0;
     out->reference_order_forced = pass->mesh_level_valid && pass->scene_level_valid && !(pass->mesh_level.nested && pass->scene_level.nested) ? 1 : 0;

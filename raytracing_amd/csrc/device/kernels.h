@@ -63,7 +63,8 @@ struct DrawParams {
     // outputs
     float *o_direct, *o_indirect, *o_albedo, *o_motion, *o_depth, *o_normal, *o_inst;
     // counters: [0] samples, [1] extend rays, [2] shadow rays, [3] draws, [4] extend rays re-traced in reference order,
-    // [5] light samples that needed no occlusion query, [6] extend rays of vertex 1 walked as groups
+    // [5] light samples that needed no occlusion query, [6] extend rays of vertex 1 walked as groups, [7] occlusion
+    // queries of vertex 0 walked as groups
     unsigned long long *stats;
     int redo_counter_base;  // index in `counters` of the per-vertex re-trace counts, -1 when there are none
     // per-draw queue counters, zeroed before generate: [d] = paths alive at vertex d
@@ -147,7 +148,12 @@ int packet_stack_entries();
 void launch_primary_shade_packets(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter,
                                   unsigned *redo, unsigned *redo_count, unsigned *queue_out, unsigned *count_out,
                                   unsigned *shadow_queue, unsigned *shadow_count, unsigned *packet_queue, unsigned *packet_count,
-                                  unsigned *packet_valid);
+                                  unsigned *packet_valid, unsigned *sgroup_queue, unsigned *sgroup_count, unsigned *sgroup_valid);
+// (sgroup_*: the same for the sky's light samples of a tile that point one way -- instead of in shadow_queue; such groups
+// want launch_shadow_packets)
+void launch_shadow_packets(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *group_count,
+                           const unsigned *valid_count, const PathRay *rays, const ShadowEntry *shadow, const PathThroughput *thr,
+                           PathAccum *acc, unsigned *next_counter, unsigned *redo, unsigned *redo_count, unsigned long long *stats);
 // extend rays of those groups, one wave per group (hits and the list of undecided slots as launch_extend_fast)
 void launch_extend_packets(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *group_count,
                            const PathRay *rays, PathHit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count);

@@ -77,11 +77,12 @@ __device__ __forceinline__ void write_shadow(ShadowEntry *e, V3 d, float dis2, V
 // (throughput update, escape to the sky) and the launches of later vertices none of the first-hit outputs.
 // given: the closest hit of the slot's ray when the caller holds it in registers (the launch that traces the camera rays
 // and shades their hits in one go); null: it is read from dp.hits[i].
-// next_dir: when not null and the path continues, the direction of its next ray (what was stored in dp.rays[i]).
+// next_dir: when not null and the path continues, the direction of its next ray (what was stored in dp.rays[i]);
+// sky_dir: when not null, the direction of the sky's light sample (what was stored in dp.shadow[i]).
 template <int RASTER, bool FIRST>
 __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsigned i, const unsigned *s_T, bool &continues,
                                              bool &has_shadow, unsigned &null_shadow, const LaneHit *given = nullptr,
-                                             V3 *next_dir = nullptr) {
+                                             V3 *next_dir = nullptr, V3 *sky_dir = nullptr) {
     continues = false;
     has_shadow = false;
     null_shadow = 0u;
@@ -311,6 +312,7 @@ __device__ __forceinline__ void shade_vertex(const DrawParams &dp, int dep, unsi
             }
         }
         write_shadow(dp.shadow + i, gwo, S_INF, recv, flags);
+        if(sky_dir) *sky_dir = gwo;
     }
     // ---- analytic lights, :531-554
     for(int li = 0; li < P.lightCount; li++) {

@@ -250,6 +250,9 @@ constexpr int PRIMARY_SHADE_ROUND = RT_PRIMARY_SHADE_ROUND;
 #ifndef RT_PACKET_MIN_LANES
 #define RT_PACKET_MIN_LANES 32
 #endif
+#ifndef RT_SHADOW_CONE_COS
+#define RT_SHADOW_CONE_COS 0.995f
+#endif
 constexpr unsigned PACKET_NONE = 0xFFFFFFFFu;
 
 // floats as unsigned integers in the same order (NaNs beyond the infinities)
@@ -268,21 +271,48 @@ struct PrimaryShadeSink {
     unsigned *stage;       // this wave's PRIMARY_SHADE_ROUND x 64 words of LDS
     unsigned *queue_out, *count_out, *shadow_queue, *shadow_count;
     unsigned *packet_queue, *packet_count, *packet_valid;  // groups of coherent bounce rays (null: none are made)
+    unsigned *sgroup_queue, *sgroup_count, *sgroup_valid;  // groups of coherent occlusion queries (null: none are made)
     unsigned staged, cont_bits, shad_bits, null_count;
     unsigned group_tiles;  // bit u: staged tile u goes to the packet queue (the same in every lane)
     unsigned group_bits;   // bit u: this lane's path of staged tile u is one of that group
+    unsigned sgroup_tiles, sgroup_bits;  // the same for the occlusion queries of the tile's light samples
 
     __device__ void tile(unsigned i, bool pixel, const LaneHit &h, bool ambiguous) {
         const unsigned lane = threadIdx.x & 63u;
         bool continues = false, has_shadow = false;
-        V3 nd = v3(0.0f);
+        V3 nd = v3(0.0f), sd = v3(0.0f);
         if(pixel) {
             if(ambiguous) {
                 PrimarySinkFast{dp, redo, redo_count, 0u}.store(i, h, true);
             } else {
                 unsigned null_shadow;
-                shade_vertex<0, true>(dp, 0, i, s_T, continues, has_shadow, null_shadow, &h, &nd);
+                shade_vertex<0, true>(dp, 0, i, s_T, continues, has_shadow, null_shadow, &h, &nd, &sd);
                 null_count += null_shadow;
+            }
+        }
+        // The light samples of a tile: an importance-sampled sky sends most of them to its few brightest texels (the sun),
+        // i.e. from neighbouring points in nearly one direction.  Those that lie within a cone about one of them -- the
+        // first lane's sample, or, when that one is a stray, the first one outside its cone -- are listed as a group.
+        if(sgroup_queue && __popcll(__ballot(has_shadow)) >= RT_PACKET_MIN_LANES) {
+            unsigned long long todo = __ballot(has_shadow);
+            bool in = false;
+#pragma unroll 1
+            for(int attempt = 0; attempt < 2 && todo; attempt++) {
+                const int ref = __builtin_ctzll(todo);
+                const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sd.x), ref));
+                const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sd.y), ref));
+                const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sd.z), ref));
+                in = has_shadow && (sd.x * ax + sd.y * ay) + sd.z * az > RT_SHADOW_CONE_COS;
+                const unsigned long long m = __ballot(in);
+                if(__popcll(m) >= RT_PACKET_MIN_LANES) break;
+                in = false;
+                todo &= ~m;
+                todo &= ~(1ull << ref);
+            }
+            if(__any(in)) {
+                sgroup_tiles |= 1u << staged;
+                sgroup_bits |= (in ? 1u : 0u) << staged;
+                if(in) has_shadow = false;  // not in the queue of occlusion queries
             }
         }
         if(packet_queue && __popcll(__ballot(continues)) >= RT_PACKET_MIN_LANES) {
@@ -321,6 +351,25 @@ struct PrimaryShadeSink {
                 }
             group_tiles = group_bits = 0u;
         }
+        if(sgroup_tiles) {
+            const unsigned n_groups = (unsigned)__popc(sgroup_tiles);
+            unsigned valid = 0u;
+#pragma unroll 1
+            for(unsigned u = 0; u < staged; u++) valid += (unsigned)__popcll(__ballot((sgroup_bits >> u) & 1u));
+            unsigned g = 0u;
+            if(lane == 0u) {
+                g = atomicAdd(sgroup_count, n_groups);
+                atomicAdd(sgroup_valid, valid);
+            }
+            g = __builtin_amdgcn_readfirstlane(g);
+#pragma unroll 1
+            for(unsigned u = 0; u < staged; u++)
+                if((sgroup_tiles >> u) & 1u) {
+                    sgroup_queue[(size_t)g * 64u + lane] = ((sgroup_bits >> u) & 1u) ? stage[u * 64u + lane] : PACKET_NONE;
+                    ++g;
+                }
+            sgroup_tiles = sgroup_bits = 0u;
+        }
         unsigned tot_c = 0u, tot_s = 0u;
 #pragma unroll 1
         for(unsigned u = 0; u < staged; u++) {
@@ -354,7 +403,8 @@ struct PrimaryShadeSink {
 
 __global__ __launch_bounds__(FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void primary_shade_packet_kernel(
     FastScene sc, DrawParams dp, unsigned *next_counter, unsigned *redo, unsigned *redo_count, unsigned *queue_out, unsigned *count_out,
-    unsigned *shadow_queue, unsigned *shadow_count, unsigned *packet_queue, unsigned *packet_count, unsigned *packet_valid) {
+    unsigned *shadow_queue, unsigned *shadow_count, unsigned *packet_queue, unsigned *packet_count, unsigned *packet_valid,
+    unsigned *sgroup_queue, unsigned *sgroup_count, unsigned *sgroup_valid) {
     __shared__ __align__(16) unsigned s_V[SOBOL_NIBBLE_WORDS];
     __shared__ unsigned s_stage[PRIMARY_SHADE_ROUND * FAST_BLOCK];
     __shared__ unsigned s_null;
@@ -369,7 +419,8 @@ __global__ __launch_bounds__(FAST_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
         dp.counters[0] = (unsigned)dp.npix;  // every slot is in the first queue
     }
     PrimaryShadeSink sink{dp, redo, redo_count, s_V, s_stage + (threadIdx.x >> 6) * (PRIMARY_SHADE_ROUND * 64), queue_out, count_out,
-                          shadow_queue, shadow_count, packet_queue, packet_count, packet_valid, 0u, 0u, 0u, 0u, 0u, 0u};
+                          shadow_queue, shadow_count, packet_queue, packet_count, packet_valid, sgroup_queue, sgroup_count, sgroup_valid,
+                          0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     trace_flat_packets(sc, CameraRays{dp, 0u}, sink, next_counter, (unsigned)dp.npix);
     if(sink.null_count) atomicAdd(&s_null, sink.null_count);
     __syncthreads();
@@ -587,6 +638,49 @@ __global__ __launch_bounds__(TRACE_BLOCK) void path_redo_kernel(TraceScene sc, c
     trace_persistent<SparseRayFeed>(sc, src, sink, next_counter, *count, s_stack);
 }
 
+// The occlusion queries of the groups the launch of vertex 0 listed (sky samples of a tile that point one way): one wave
+// per group on one node sequence, every lane out at its first hit; a visible sample goes into its path's accumulator
+// where the walk ends, as in the merged launch, and a query given up by rule (5) onto the same list, tagged.
+struct QueuedShadowRays {
+    const unsigned *queue;
+    const PathRay *rays;
+    const ShadowEntry *shadow;
+    __device__ bool make(unsigned item, unsigned &slot, V3 &o, V3 &d) const {
+        const unsigned e = queue[item];
+        if(e == PACKET_NONE) return false;
+        slot = e;
+        const float4 a = reinterpret_cast<const float4 *>(shadow + e)[0];
+        const float4 ro = *reinterpret_cast<const float4 *>(rays + e);
+        o = v3(ro.x, ro.y, ro.z);
+        d = v3(a.x, a.y, a.z);
+        return true;
+    }
+};
+struct GroupShadowSink {
+    const ShadowEntry *shadow;
+    const PathThroughput *thr;
+    PathAccum *acc;
+    unsigned *redo, *redo_count;
+    __device__ void tile(unsigned slot, bool has_ray, const LaneHit &h, bool ambiguous) const {
+        if(!has_ray) return;
+        if(ambiguous) redo[atomicAdd(redo_count, 1u)] = slot | REDO_SHADOW;
+        else apply_sky_sample(shadow, thr, acc, slot, h);
+    }
+    __device__ void finish() const {}
+};
+__global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void shadow_packet_kernel(FastScene sc, const unsigned *queue, const unsigned *group_count,
+                                                                   const unsigned *valid_count, const PathRay *rays,
+                                                                   const ShadowEntry *shadow, const PathThroughput *thr, PathAccum *acc,
+                                                                   unsigned *next_counter, unsigned *redo, unsigned *redo_count,
+                                                                   unsigned long long *stats) {
+    if(blockIdx.x == 0 && threadIdx.x == 0 && *valid_count) {
+        atomicAdd(stats + 2, (unsigned long long)*valid_count);  // occlusion queries traced
+        atomicAdd(stats + 7, (unsigned long long)*valid_count);  // ... as groups
+    }
+    GroupShadowSink sink{shadow, thr, acc, redo, redo_count};
+    trace_flat_packets<true>(sc, QueuedShadowRays{queue, rays, shadow}, sink, next_counter, *group_count * 64u);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(FAST_BLOCK) RT_FAST_OCC void path_trace_fast_kernel(
     FastScene sc, const unsigned *queue_e, const unsigned *count_e, const unsigned *queue_s, const unsigned *count_s,
@@ -622,9 +716,16 @@ void launch_primary_fast(hipStream_t s, const FastScene &sc, int blocks, const D
 void launch_primary_shade_packets(hipStream_t s, const FastScene &sc, int blocks, const DrawParams &dp, unsigned *next_counter,
                                   unsigned *redo, unsigned *redo_count, unsigned *queue_out, unsigned *count_out,
                                   unsigned *shadow_queue, unsigned *shadow_count, unsigned *packet_queue, unsigned *packet_count,
-                                  unsigned *packet_valid) {
+                                  unsigned *packet_valid, unsigned *sgroup_queue, unsigned *sgroup_count, unsigned *sgroup_valid) {
     hipLaunchKernelGGL(primary_shade_packet_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, dp, next_counter, redo, redo_count,
-                       queue_out, count_out, shadow_queue, shadow_count, packet_queue, packet_count, packet_valid);
+                       queue_out, count_out, shadow_queue, shadow_count, packet_queue, packet_count, packet_valid, sgroup_queue, sgroup_count,
+                       sgroup_valid);
+}
+void launch_shadow_packets(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *group_count,
+                           const unsigned *valid_count, const PathRay *rays, const ShadowEntry *shadow, const PathThroughput *thr,
+                           PathAccum *acc, unsigned *next_counter, unsigned *redo, unsigned *redo_count, unsigned long long *stats) {
+    hipLaunchKernelGGL(shadow_packet_kernel, dim3(blocks), dim3(FAST_BLOCK), 0, s, sc, queue, group_count, valid_count, rays, shadow, thr, acc,
+                       next_counter, redo, redo_count, stats);
 }
 void launch_extend_packets(hipStream_t s, const FastScene &sc, int blocks, const unsigned *queue, const unsigned *group_count,
                            const PathRay *rays, PathHit *hits, unsigned *next_counter, unsigned *redo, unsigned *redo_count) {

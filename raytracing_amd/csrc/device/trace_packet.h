@@ -56,7 +56,8 @@ struct CameraRays {  // the camera rays of the slots [base, base + n_items), sha
     }
 };
 
-template <class Rays, class Sink>
+// ANY_HIT: occlusion queries -- a lane's ray ends at the first hit it accepts.
+template <bool ANY_HIT = false, class Rays, class Sink>
 __device__ __forceinline__ void trace_flat_packets(const FastScene &sc, const Rays &rays, Sink &sink, unsigned *next_tile,
                                                    unsigned n_items) {
     WaveRayFeed feed(n_items);  // hands out whole groups: batch sizes and n_items are multiples of 64
@@ -161,6 +162,7 @@ __device__ __forceinline__ void trace_flat_packets(const FastScene &sc, const Ra
                                 best.inst = (int)inst;
                                 best_gate = fmaxf(te, tw);
                                 prune_dirty = true;
+                                if(ANY_HIT) live = false;  // (occluded: nothing more to ask)
                             }
                         } else {
                             second_t = fminf(second_t, t);
@@ -244,6 +246,7 @@ __device__ __forceinline__ void trace_flat_packets(const FastScene &sc, const Ra
                 }
             }
             // ---- the next deferred node that some lane still wants
+            if(ANY_HIT && !have && !__any(live)) sp = 0;  // (every query of the group is answered)
             while(!have && sp > 0) {
                 --sp;
                 ref = (unsigned)__builtin_amdgcn_readlane(st_ref, sp);
@@ -259,7 +262,8 @@ __device__ __forceinline__ void trace_flat_packets(const FastScene &sc, const Ra
         bool ambiguous = false;
         if(pixel) {
             const bool odd = best_gate > best.t * 1.0005f + 4.0f * abs_slack;
-            ambiguous = uncertain || (best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f));
+            // (occlusion queries have no order dependence: only a ray given up by rule (5) is undecided)
+            ambiguous = uncertain || (!ANY_HIT && best.tri >= 0 && (odd || second_t <= best.t || second_t < best_gate * 1.000004f));
             if(ambiguous && odd) best.t = RT_INF;
             if(uncertain) {
                 best.t = RT_INF; best.tri = -1; best.inst = -1;

@@ -251,7 +251,8 @@ class PathTracingPass:
                     draws=int(s.draws), rays_retraced=int(s.rays_retraced), mesh_level_builds=int(s.mesh_level_builds),
                     scene_level_builds=int(s.scene_level_builds), debug=[int(x) for x in s.debug],
                     reference_order_forced=int(s.reference_order_forced), flat_leaves=int(s.flat_leaves),
-                    rays_shadow_null=int(s.rays_shadow_null), rays_extend_grouped=int(s.rays_extend_grouped))
+                    rays_shadow_null=int(s.rays_shadow_null), rays_extend_grouped=int(s.rays_extend_grouped),
+                    rays_shadow_grouped=int(s.rays_shadow_grouped))
 
     def prepare(self):
         """Validates the bound scene buffers and builds the traversal arrays now instead of inside the next draw."""

@@ -44,7 +44,7 @@ def test_param_struct_sizes_match_between_binding_and_oracle():
     from raytracing_amd import _capi
     # pt_params: 2+1+1+16+4+1+2+1+1+2+16+4+1+1+7 = 60 words
     assert ctypes.sizeof(_capi.PtParams) == 60 * 4
-    assert ctypes.sizeof(_capi.PtStats) == 14 * 8
+    assert ctypes.sizeof(_capi.PtStats) == 15 * 8
 
 
 def test_cpp_facade_compiles():

@@ -82,8 +82,9 @@ def run(n_scenes, seed, ctx, verbose=True):
         fails = []
         for traversal in (0, 1, 2, 3):
             # single draws; the three samples as one draw with the scene laid out ahead (camera rays as tiles, shaded where they
-            # are traced); one sample, then two in one draw (whose halves go through the two kinds of primary launch)
-            for pipeline, tail, how in ((3, -1, "single"), (1, 1 << 30, "single"), (1, 0, "single"), (1, -1, "batch"), (3, -1, "1+2")):
+            # are traced -- with the tail launch off also the groups of rays that leave a tile together); one sample, then two
+            # in one draw
+            for pipeline, tail, how in ((3, -1, "single"), (1, 1 << 30, "single"), (1, 0, "single"), (1, -1, "batch"), (1, 0, "batch"), (3, -1, "1+2")):
                 p = device.PathTracingPass(ctx, w, h)
                 p.bind_scene(sb)
                 p.set_traversal(traversal)
