@@ -31,6 +31,7 @@ constexpr int CNT_SGROUPS = 429;    // the same three for the groups of occlusio
 constexpr int CNT_SHADOW_REDO = 432;       // [432, 502): occlusion queries the ordered traversal left undecided, per vertex
 constexpr int CNT_NEXT_SHADOW_REDO = 502;  // [502, 572): next-ray counters of the launches that trace those
 constexpr int CNT_TOTAL = 572;
+constexpr size_t GROUPS_FROM_SLOTS = 6000000;  // path slots from which a draw walks coherent bounce rays as groups (three samples at 1920x1080: measured even at two, 2 % faster at four)
 
 struct DeviceArray {
     void *p = nullptr;
@@ -1293,9 +1294,14 @@ int draw_samples(pt_pass *p, const pt_params *prms, int n) {
     const bool fuse_first = !fusion_off && fused_primary && packets && tuner_kind < 0 && !tuner_halves && !p->profiling && !dp.raster_outputs &&
                             tail_from != 0 && p->material_grouping <= 0;
     // Tiles whose paths leave in nearly one direction (a polished floor, a pane) are walked as groups once more at vertex 1
-    // (trace_kernels.hip: extend_packet_kernel); RTA_BOUNCE_GROUPS=0: all through the merged launch, a tuning aid.
-    static const bool groups_off = getenv("RTA_BOUNCE_GROUPS") && atoi(getenv("RTA_BOUNCE_GROUPS")) == 0;
-    const bool bounce_groups = fuse_first && !groups_off && merged && tail_from != 1 && P.MAX_DEPTH >= 1;
+    // (trace_kernels.hip: extend_packet_kernel) -- in a draw fat enough for a launch over some of its tiles to fill the chip:
+    // the walk of a group is one dependent chain per wave, and a thin launch of such walks waits for its slowest
+    // (single 1920x1080 samples: 2.91 -> 3.44 ms with groups, sixteen samples in a draw: 1.47 -> 1.40 ms per sample).
+    // RTA_BOUNCE_GROUPS=0: never, 2: whenever possible (tuning and test aid, read at every draw).
+    const char *groups_env = getenv("RTA_BOUNCE_GROUPS");
+    const int groups_mode = groups_env ? atoi(groups_env) : 1;
+    const bool bounce_groups = fuse_first && groups_mode != 0 && merged && tail_from != 1 && P.MAX_DEPTH >= 1 &&
+                               (groups_mode == 2 || npix >= GROUPS_FROM_SLOTS);
     unsigned *qp = bounce_groups ? static_cast<unsigned *>(L.queue_p.p) : nullptr;
     static const bool sgroups_off = getenv("RTA_SHADOW_GROUPS") && atoi(getenv("RTA_SHADOW_GROUPS")) == 0;
     unsigned *qps = bounce_groups && !sgroups_off ? static_cast<unsigned *>(L.queue_ps.p) : nullptr;

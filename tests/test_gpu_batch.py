@@ -188,36 +188,41 @@ def test_rays_that_leave_a_tile_together_are_walked_together(gpu_ctx, casa, orac
     point at the sun of the benchmark's sky (at 2048x1024 its bright texels lie within a few degrees; the small sky of
     the other tests spreads them too far).  Outputs and ray counts must not know."""
     from raytracing_amd import device, scene
+    import os
     small_sky = scene.procedural_sky(2048, 1024)
     w, h, depth = 320, 180, 5
-    sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
-    p = device.PathTracingPass(gpu_ctx, w, h)
-    p.bind_scene(sb)
-    p.set_tail_threshold(0)   # every vertex in launches of its own (a small frame would hand vertex 1 to the tail launch)
-    p.prepare()
-    prms = params_of(scene, casa, small_sky, scene.casa_camera(), w, h, [1, 2, 3, 4], depth)
-    osc = oracle_mod.OracleScene(casa, small_sky)
-    acc, cnt = None, dict(rays_extend=0, rays_shadow=0)
-    for prm in prms:
-        acc, c = osc.render(prm, acc)
-        for k in cnt:
-            cnt[k] += c[k]
-    p.stats(reset=True)
-    got, st = batched(p, prms, [4])
-    assert st["rays_extend_grouped"] > 0.1 * w * h * 4, st   # (a third of this view's first hits lie on such surfaces)
-    assert st["rays_shadow_grouped"] > 0.2 * w * h * 4, st
-    assert st["rays_extend"] == cnt["rays_extend"] and st["rays_shadow"] == cnt["rays_shadow"]
-    for k in acc:
-        assert words_equal(got[k], acc[k].reshape(got[k].shape)), k
-    # single draws and the per-kernel profile take other routes to the same frame
-    got1, st1 = one_by_one(p, prms)
-    p.set_profiling(True)
-    got2, st2 = batched(p, prms, [4])
-    p.set_profiling(False)
-    assert st2["rays_extend_grouped"] == 0 and st2["rays_shadow_grouped"] == 0
-    for k in acc:
-        assert words_equal(got1[k], acc[k].reshape(got1[k].shape)) and words_equal(got2[k], acc[k].reshape(got2[k].shape)), k
-    for k in ("rays_extend", "rays_shadow", "rays_shadow_null"):
-        assert st[k] == st1[k] == st2[k], k
+    os.environ["RTA_BOUNCE_GROUPS"] = "2"   # (the library makes groups only in draws of millions of paths)
+    try:
+        sb = device.SceneBuffers(gpu_ctx, casa, small_sky)
+        p = device.PathTracingPass(gpu_ctx, w, h)
+        p.bind_scene(sb)
+        p.set_tail_threshold(0)   # every vertex in launches of its own (a small frame would hand vertex 1 to the tail launch)
+        p.prepare()
+        prms = params_of(scene, casa, small_sky, scene.casa_camera(), w, h, [1, 2, 3, 4], depth)
+        osc = oracle_mod.OracleScene(casa, small_sky)
+        acc, cnt = None, dict(rays_extend=0, rays_shadow=0)
+        for prm in prms:
+            acc, c = osc.render(prm, acc)
+            for k in cnt:
+                cnt[k] += c[k]
+        p.stats(reset=True)
+        got, st = batched(p, prms, [4])
+        assert st["rays_extend_grouped"] > 0.1 * w * h * 4, st   # (a third of this view's first hits lie on such surfaces)
+        assert st["rays_shadow_grouped"] > 0.2 * w * h * 4, st
+        assert st["rays_extend"] == cnt["rays_extend"] and st["rays_shadow"] == cnt["rays_shadow"]
+        for k in acc:
+            assert words_equal(got[k], acc[k].reshape(got[k].shape)), k
+        # single draws and the per-kernel profile take other routes to the same frame
+        got1, st1 = one_by_one(p, prms)
+        p.set_profiling(True)
+        got2, st2 = batched(p, prms, [4])
+        p.set_profiling(False)
+        assert st2["rays_extend_grouped"] == 0 and st2["rays_shadow_grouped"] == 0
+        for k in acc:
+            assert words_equal(got1[k], acc[k].reshape(got1[k].shape)) and words_equal(got2[k], acc[k].reshape(got2[k].shape)), k
+        for k in ("rays_extend", "rays_shadow", "rays_shadow_null"):
+            assert st[k] == st1[k] == st2[k], k
+    finally:
+        del os.environ["RTA_BOUNCE_GROUPS"]
     p.destroy()
     sb.release()

@@ -9,6 +9,7 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("RTA_BOUNCE_GROUPS", "2")   # rays that leave a tile together walked as groups however small the draw
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
