@@ -562,9 +562,17 @@ def main():
                         # total bytes of those kernels over the profiled run / number of main launches
                         tot = sum((pmc[n]["FETCH_SIZE"]["total"] + pmc[n]["WRITE_SIZE"]["total"]) * 1024.0 for n in have)
                         n_launch = sum(pmc[n]["FETCH_SIZE"]["launches"] for n in main)
-                        if pmc.get("_meta", {}).get("hbm_bytes_per_sample"):
-                            # every kernel of a frame's sample (traversal, shading, finalize): bytes that crossed the HBM interface
-                            out["hbm_bytes_per_sample_measured"] = pmc["_meta"]["hbm_bytes_per_sample"]
+                        # every kernel of a frame's sample (traversal, shading, finalize): bytes that crossed the HBM interface,
+                        # from the counter passes of the draws as shipped when there are such (the passes behind `traffic` have
+                        # every stage in a launch of its own, as the launches timed here)
+                        shipped = pmc_file.replace(".json", "_shipped.json")
+                        meta = pmc.get("_meta", {})
+                        if os.path.exists(shipped):
+                            sm = json.load(open(shipped)).get("_meta", {})
+                            if sm.get("kernel_sources_sha256") == kernel_sources_digest() and sm.get("hbm_bytes_per_sample"):
+                                meta = sm
+                        if meta.get("hbm_bytes_per_sample"):
+                            out["hbm_bytes_per_sample_measured"] = meta["hbm_bytes_per_sample"]
                         rf["traffic"] = tot / max(n_launch, 1)
                         rf["traffic_source"] = "profiles/" + os.path.basename(pmc_file)
                         pmc_batch = pmc.get("_meta", {}).get("samples_per_draw")

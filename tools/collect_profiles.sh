@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 what=$1; tag=$2; r=${3:-r03}
 if [ "$what" = pmc ]; then
-  for w in casa_pt casa_isect synth_pt; do
+  for w in casa_pt casa_pt_shipped casa_isect synth_pt; do
     cp gpurun_out/${r}_pmc_$w.json profiles/${r}_pmc_$w.json && cp gpurun_out/${r}_pmc_$w.txt profiles/${r}_pmc_$w.txt || exit 1
   done
   for w in casa_pt casa_pt_batch_serial casa_pt_serial casa_isect synth_pt; do
