@@ -115,5 +115,28 @@ def test_capi_allreduce_world_of_one(gpu_ctx, casa, small_sky):
     with pytest.raises(_capi.PtError):
         comm.allreduce(p, spp, 1)
     comm.destroy()
+    # the single-process form (one host thread, several contexts: the reference's main.cpp shape) with its one context
+    import ctypes as C
+    ctxs = (C.c_void_p * 1)(gpu_ctx.h)
+    comms = (C.c_void_p * 1)()
+    _capi.check(_capi.lib.pt_comm_create_all(ctxs, 1, comms))
+    passes = (C.c_void_p * 1)(p.h)
+    for name in multigpu.ACCUMULATED:
+        p.outputs[name].fill(0.0)
+    frame(1)
+    _capi.check(_capi.lib.pt_pass_allreduce_all(passes, comms, 1, spp, 0))
+    got_all = p.download()
+    for name in got:
+        assert np.array_equal(got_all[name].view(np.uint32), got[name].view(np.uint32)), name
+    # its arguments are checked before anything is queued
+    for bad in (lambda: _capi.lib.pt_pass_allreduce_all(passes, comms, 1, 0, 0), lambda: _capi.lib.pt_pass_allreduce_all(passes, comms, 1, spp, 1),
+                lambda: _capi.lib.pt_pass_allreduce_all(passes, comms, 0, spp, 0), lambda: _capi.lib.pt_pass_allreduce_all(None, comms, 1, spp, 0),
+                lambda: _capi.lib.pt_pass_allreduce_all((C.c_void_p * 1)(None), comms, 1, spp, 0)):
+        with pytest.raises(_capi.PtError):
+            _capi.check(bad())
+    two = (C.c_void_p * 2)(gpu_ctx.h, gpu_ctx.h)
+    with pytest.raises(_capi.PtError, match="one rank per GPU"):
+        _capi.check(_capi.lib.pt_comm_create_all(two, 2, (C.c_void_p * 2)()))
+    _capi.check(_capi.lib.pt_comm_destroy(comms[0]))
     p.destroy()
     sb.release()
