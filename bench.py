@@ -74,6 +74,8 @@ def parse():
                     help="pt_pass_set_material_grouping: -1 the library's choice (a lone draw: escaped paths apart from vertex 1 on), 0 no grouping, 1 by material type")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank control flow on ONE GPU: all ranks use device 0, gloo backend, collectives staged through the host")
+    ap.add_argument("--batches", default=None,
+                    help="explicit draw sizes of the timed region, e.g. 4,8,8 (a tuning aid; overrides --batch for the timed region)")
     ap.add_argument("--one-scaling", action="store_true", help="with --gpus N > 1: do not time the other scaling mode as well")
     ap.add_argument("--dump", default=None, help="rank 0 writes the final output buffers to this .npz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -242,6 +244,12 @@ def main():
         def draw_all(prms, batch=None):
             """The samples in order: one pt_pass_draw each, or pt_pass_draw_batch calls of --batch samples."""
             batch = batch or args.batch
+            if args.batches and len(prms) == sum(int(x) for x in args.batches.split(",")):
+                k = 0
+                for b in (int(x) for x in args.batches.split(",")):
+                    p.draw_batch(prms[k:k + b])
+                    k += b
+                return
             if batch <= 1:
                 for prm in prms:
                     p.set_params(prm)
