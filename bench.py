@@ -607,13 +607,18 @@ def main():
                             rf["valu_issue_busy"] = tot_of("SQ_INSTS_VALU") * 4.0 / (tot_of("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)
                         if "SQ_INSTS_SALU" in m and "SQ_INSTS_VALU" in m:
                             rf["salu_per_valu_inst"] = tot_of("SQ_INSTS_SALU") / tot_of("SQ_INSTS_VALU")
+                        if rf.get("valu_issue_busy") and rf.get("lanes_active_per_valu_inst"):
+                            # the roof this kernel is under: vector lanes.  Share of the chip's lane-cycles (1024 SIMDs x 16 lanes)
+                            # that did work = share of cycles a SIMD issued a vector instruction x share of its 64 lanes active
+                            rf["valu_lane_frac"] = rf["valu_issue_busy"] * rf["lanes_active_per_valu_inst"] / 64.0
                         if rf["hbm_frac_measured"] < 0.3:
                             rf["bound"] = "valu-issue/latency"
                         rf["note"] = ("frac = the REFERENCE algorithm's bytes per ray (48-byte nodes in its visiting order, counted by "
                                       "the oracle) x rays / kernel time / 8 TB/s; it is not bandwidth: the kernel answers the same queries "
                                       "with far fewer bytes.  hbm_frac_measured = bytes the kernel really moved (PMC) / kernel time / 8 TB/s; "
                                       "below 0.3 the kernel is bound by vector-ALU issue and latency (valu_issue_busy, "
-                                      "lanes_active_per_valu_inst of 64), not by HBM.")
+                                      "lanes_active_per_valu_inst of 64; valu_lane_frac = their product / 64 = the share of the chip's "
+                                      "vector lane-cycles that did work), not by HBM.")
             if prof:
                 out["kernel_ms"] = {k: prof[k] for k in ("extend_ms", "trace_ms", "shadow_ms", "shade_ms", "other_ms", "intersect_ms", "tail_ms")}
                 if "draws" in prof:
