@@ -17,6 +17,7 @@
 // channel (SSBOBuffer.h, RenderPass.cpp:60-84 print and continue); here every failed call
 // throws std::runtime_error carrying pt_last_error().
 #pragma once
+#include <algorithm>
 #include <cassert>
 #include <cstring>
 #include <stdexcept>
@@ -181,6 +182,8 @@ class Renderer : public RenderPass {
     pt_pass *m_pass = nullptr;
     pt_params m_params;
     int m_w, m_h;
+    bool m_batching = false;
+    std::vector<pt_params> m_batch;
     template <class V>
     static bool is(const char *a, const char *b, V) { return !strcmp(a, b); }
 public:
@@ -272,8 +275,27 @@ public:
         rm->lightSSBO.bind_current_shader(6);
         uniform1i("lightCount", rm->getLightCount());
         current_pass() = prev ? prev : this;
+        if(m_batching) {  // (between begin_batch and end_batch a draw only records its sample's uniform block)
+            m_batch.push_back(m_params);
+            return;
+        }
         check(pt_pass_set_params(m_pass, &m_params));
         check(pt_pass_draw(m_pass));  // was: drawcall()
+    }
+
+    // No counterpart in the reference.  Its frame is `for(spp = 1 .. Config::SPP) { uniforms; renderPass->draw(); }`
+    // (main.cpp:169-208); with begin_batch() before that loop and end_batch() behind it the loop stays as it is, and the
+    // samples it drew are handed over together, sixteen at a time (pt_pass_draw_batch: one set of launches per call; same
+    // outputs).  The samples of a batch may differ in jitter, currentspp and frameCounter only.
+    void begin_batch() {
+        m_batching = true;
+        m_batch.clear();
+    }
+    void end_batch() {
+        m_batching = false;
+        for(size_t k = 0; k < m_batch.size(); k += 16)
+            check(pt_pass_draw_batch(m_pass, m_batch.data() + k, (int)std::min<size_t>(16, m_batch.size() - k)));
+        m_batch.clear();
     }
 };
 

@@ -145,6 +145,8 @@ int main(int argc, char **argv) {
         if(pbytes.size() != sizeof(pt_params) * (size_t)SPP) throw std::runtime_error("params.bin has the wrong size");
         const pt_params *P = reinterpret_cast<const pt_params *>(pbytes.data());
         for(int frame = 1; frame <= 2; frame++) {
+            // (the second frame hands its samples over as one batch: the loop is the same, the draws are recorded)
+            if(frame == 2) renderPass->begin_batch();
             for(int spp = 1; spp <= SPP; spp++) {
                 const pt_params &q = P[spp - 1];
                 renderPass->use();
@@ -174,6 +176,7 @@ int main(int argc, char **argv) {
                 }
                 renderPass->draw();
             }
+            if(frame == 2) renderPass->end_batch();
             svgfMergePass->use();
             svgfMergePass->uniform1i("SCREEN_W", W);
             svgfMergePass->draw(renderPass->directLumGBufferSSBO, renderPass->indirectLumGBufferSSBO, renderPass->albedoGBufferSSBO);
